@@ -1,0 +1,85 @@
+"""The CPU oracle (oracle/tcvn_oracle.py) against golden vectors produced by the real reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tcvn_oracle as O
+from golden_utils import load_case, train_cfg, rel_err, tap_sample
+
+def is_noise_grad(key):
+    """Every DenseNet conv bias feeds (only) train-mode BatchNorms, so its exact gradient is 0 and what the
+    reference reports is fp32 rounding noise (~1e-4) -- compare those by magnitude only."""
+    return "pixel_embedding.features" in key and key.endswith(("conv0.bias", "conv1.bias", "conv2.bias", "conv.bias"))
+
+
+def grad_close(key, mine, ref, rtol=6e-3):
+    # fp32 backward through 65 conv layers: the reference's own gradients sit 1-2e-3 (max-norm) from an fp64
+    # evaluation of the same graph (measured), so fp32-vs-fp32 comparisons get a 6e-3 band.
+    floor = 5e-3 if is_noise_grad(key) else 1e-6         # exact-zero gradients show up as rounding noise
+    if np.abs(mine).max() < floor and np.abs(ref).max() < floor:
+        return True
+    return rel_err(mine, ref) < rtol
+
+
+CASES = ["small_b3", "tutorial_b2p4", "tutorial_ragged"]
+
+
+def test_state_layout_matches_reference_counts():
+    lay = O.state_layout(O.tutorial_config())
+    assert len(lay) == 1208
+    assert sum(int(np.prod(s)) if len(s) else 1 for s in lay.values()) == 5779136
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_eval_logits(name):
+    cfg, over, batch, g = load_case(name)
+    sd = O.fill_state(cfg, int(g["weight_seed"]))
+    with torch.no_grad():
+        et, pt, ev, pr, ctx = O.shared_step(sd, cfg, batch, training=False)
+    assert rel_err(ev, g["eval_event_logits"]) < 2e-5
+    assert rel_err(pr, g["eval_prong_logits"]) < 2e-5
+    # events must not be degenerate copies of each other (SURVEY.md 7 'Degenerate goldens')
+    assert np.abs(g["eval_event_logits"][0] - g["eval_event_logits"][1]).max() > 1e-3
+    for k, t in ctx.taps.items():
+        if "evaltap_stat:" + k in g:
+            s, smp = tap_sample(t)
+            assert rel_err(smp, g["evaltap_samp:" + k]) < 5e-5, k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_step(name):
+    cfg, over, batch, g = load_case(name)
+    cfgt = train_cfg(over)
+    sd = O.fill_state(cfgt, int(g["weight_seed"]))
+    (total, el, pl), (ev, pr), grads, ctx = O.train_step(sd, cfgt, batch)
+    assert abs(total.item() - float(g["train_total_loss"])) < 2e-5 * abs(float(g["train_total_loss"]))
+    assert abs(el.item() - float(g["train_event_loss"])) < 5e-5
+    assert abs(pl.item() - float(g["train_prong_loss"])) < 5e-5
+    assert rel_err(ev, g["train_event_logits"]) < 5e-5
+    assert rel_err(pr, g["train_prong_logits"]) < 5e-5
+    for k in [k for k in g if k.startswith("grad:")]:
+        assert grad_close(k[5:], grads[k[5:]].numpy(), g[k]), k
+    gn = dict(zip([str(k) for k in g["grad_keys"]], g["grad_norms"]))
+    for k, v in grads.items():
+        ref = gn[k]
+        if is_noise_grad(k):
+            continue
+        assert abs(v.double().norm().item() - ref) <= 6e-3 * max(ref, 1e-6) + 1e-6, k
+    for k in [k for k in g if k.startswith("newstat:")]:
+        name_ = k[8:]
+        if name_.endswith("num_batches_tracked"):
+            continue
+        assert rel_err(ctx.new_running[name_], g[k]) < 1e-5, k
+
+
+def test_fp64_oracle_bounds_reference_noise():
+    """fp64 evaluation of the oracle vs the reference's fp32 golden: logits to 2e-5, gradients to 3e-3."""
+    cfg, over, batch, g = load_case("small_b3")
+    cfgt = train_cfg(over)
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in O.fill_state(cfgt, int(g["weight_seed"])).items()}
+    b64 = tuple(t.double() if t.is_floating_point() else t for t in batch)
+    (total, el, pl), (ev, pr), grads, ctx = O.train_step(sd, cfgt, b64)
+    assert rel_err(g["train_event_logits"], ev) < 2e-5
+    assert rel_err(g["train_prong_logits"], pr) < 2e-5
+    for k in [k for k in g if k.startswith("grad:")]:
+        assert grad_close(k[5:], g[k], grads[k[5:]].numpy(), rtol=3e-3), k
