@@ -1,0 +1,472 @@
+// DenseNet embedder engine: owns the layer schedule of layers/dense_net.py:97-167 (reference) and drives the gfx950
+// kernels on one stream.  Data layout in HBM (per call, inside the caller's workspace):
+//   img    [n,H,W,in_ch]                dense pixel map, NHWC
+//   c0     [n,H/2,W/2,init]             conv0 output (pre-BN)
+//   D[b]   [n,Hb,Wb,ld_b]               concat buffer of dense block b; layer l writes channels [C0_b+l*g, +g) in place
+//   Y[b,l] [n,Hb,Wb,bn_size*g]          bottleneck (1x1 conv) output, kept for backward
+//   bstat  (mean, biased var) per produced channel, fp64; BN (scale, shift) tables per BatchNorm layer, fp32
+// Activations are fp32 (TCVN_MODE_F32) or bf16 (TCVN_MODE_BF16); statistics and tables are always fp64/fp32.
+#include <string>
+#include <vector>
+#include <cstring>
+
+#include "../../include/tcvn_hip.h"
+#include "tcvn_ops.h"
+#include "tcvn_rows.h"
+#include "densenet_plan.h"
+
+using namespace tcvn;
+
+namespace {
+constexpr float kEps = 1e-5f, kMom = 0.1f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// plan construction
+// ---------------------------------------------------------------------------------------------------------------------
+int DenseNetPlan::add_slot(const std::string& name, long numel, int kind) {
+    slots.push_back({name, numel, kind});
+    return (int)slots.size() - 1;
+}
+BnSlots DenseNetPlan::add_bn(const std::string& p, int c) {
+    BnSlots s;
+    s.w = add_slot(p + ".weight", c, TCVN_SLOT_PARAM);
+    s.b = add_slot(p + ".bias", c, TCVN_SLOT_PARAM);
+    s.rm = add_slot(p + ".running_mean", c, TCVN_SLOT_BUFFER);
+    s.rv = add_slot(p + ".running_var", c, TCVN_SLOT_BUFFER);
+    s.nbt = add_slot(p + ".num_batches_tracked", 1, TCVN_SLOT_COUNTER);
+    s.C = c;
+    s.id = n_bn++;
+    return s;
+}
+
+DenseNetPlan::DenseNetPlan(const tcvn_densenet_cfg& c) : cfg(c) {
+    esz = cfg.mode == MODE_F32 ? 4 : 2;
+    const int g = cfg.growth, mid = cfg.bn_size * cfg.growth;
+    Hc = (cfg.H + 6 - 7) / 2 + 1; Wc = (cfg.W + 6 - 7) / 2 + 1;
+    int h = (Hc - 3) / 2 + 1, w = (Wc - 3) / 2 + 1;
+    int ch = cfg.init_ch;
+    const std::string f = "features";
+    s_w0 = add_slot(f + ".conv0.weight", (long)ch * cfg.in_ch * 49, TCVN_SLOT_PARAM);
+    s_b0 = add_slot(f + ".conv0.bias", ch, TCVN_SLOT_PARAM);
+    n0 = add_bn(f + ".norm0", ch);
+    s_a0 = add_slot(f + ".relu0.weight", ch, TCVN_SLOT_PARAM);
+    for (int b = 0; b < cfg.n_blocks; ++b) {
+        BlockGeom bg;
+        bg.H = h; bg.W = w; bg.C0 = ch; bg.L = cfg.layers[b]; bg.Ctot = ch + bg.L * g; bg.ld = (int)round_up(bg.Ctot, 8);
+        for (int l = 0; l < bg.L; ++l) {
+            LayerSlots ls;
+            const int cin = ch + l * g;
+            const std::string p = f + ".dense" + std::to_string(b + 1) + ".layers." + std::to_string(l);
+            ls.n1 = add_bn(p + ".bottleneck_block.norm1", cin);
+            ls.a1 = add_slot(p + ".bottleneck_block.relu1.weight", cin, TCVN_SLOT_PARAM);
+            ls.w1 = add_slot(p + ".bottleneck_block.conv1.weight", (long)mid * cin, TCVN_SLOT_PARAM);
+            ls.b1 = add_slot(p + ".bottleneck_block.conv1.bias", mid, TCVN_SLOT_PARAM);
+            ls.n2 = add_bn(p + ".output_block.norm2", mid);
+            ls.a2 = add_slot(p + ".output_block.relu2.weight", mid, TCVN_SLOT_PARAM);
+            ls.w2 = add_slot(p + ".output_block.conv2.weight", (long)g * mid * 9, TCVN_SLOT_PARAM);
+            ls.b2 = add_slot(p + ".output_block.conv2.bias", g, TCVN_SLOT_PARAM);
+            ls.cin = cin;
+            bg.layers.push_back(ls);
+        }
+        ch = bg.Ctot;
+        if (b != cfg.n_blocks - 1) {
+            const std::string p = f + ".transition" + std::to_string(b + 1);
+            bg.has_trans = true;
+            bg.tn = add_bn(p + ".norm", ch);
+            bg.ta = add_slot(p + ".relu.weight", ch, TCVN_SLOT_PARAM);
+            bg.tw = add_slot(p + ".conv.weight", (long)(ch / 2) * ch, TCVN_SLOT_PARAM);
+            bg.tb = add_slot(p + ".conv.bias", ch / 2, TCVN_SLOT_PARAM);
+            ch = ch / 2; h = h / 2; w = w / 2;
+        }
+        blocks.push_back(bg);
+    }
+    Cf = ch;
+    nf = add_bn(f + ".final_norm", ch);
+    s_af = add_slot(f + ".final_relu.weight", ch, TCVN_SLOT_PARAM);
+    s_wl = add_slot("output_block.linear.weight", (long)cfg.out_dim * ch, TCVN_SLOT_PARAM);
+    nl = add_bn("output_block.norm", cfg.out_dim);
+    s_al = add_slot("output_block.relu.weight", cfg.out_dim, TCVN_SLOT_PARAM);
+    data.assign(slots.size(), nullptr);
+    grad.assign(slots.size(), nullptr);
+}
+
+DenseNetPlan::~DenseNetPlan() {
+    if (d_desc) (void)hipFree(d_desc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// workspace layout
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Bump {
+    long off = 0;
+    long take(long bytes) { long o = off; off += round_up(bytes, 256); return o; }
+};
+}  // namespace
+
+void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
+    Bump b;
+    const int mid = cfg.bn_size * cfg.growth;
+    L.img = b.take((long)n * cfg.H * cfg.W * cfg.in_ch * esz);
+    L.c0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
+    L.D.clear(); L.Y.clear(); L.bstatD.clear(); L.bstatY.clear();
+    long max_part = (long)pool0_grid(n, blocks[0].H, blocks[0].W) * cfg.init_ch * 16;
+    max_part = std::max(max_part, (long)conv_fwd_grid(n * Hc * Wc) * cfg.init_ch * 16);
+    long maxY = 0;
+    for (const auto& bg : blocks) {
+        const long M = (long)n * bg.H * bg.W;
+        L.D.push_back(b.take(M * bg.ld * esz));
+        std::vector<long> ys, bs;
+        for (int l = 0; l < bg.L; ++l) { ys.push_back(b.take(M * mid * esz)); bs.push_back(b.take(mid * 16)); }
+        L.Y.push_back(ys); L.bstatY.push_back(bs);
+        L.bstatD.push_back(b.take((long)bg.ld * 16));
+        max_part = std::max(max_part, (long)conv_fwd_grid((int)M) * std::max(mid, bg.Ctot) * 16);
+        maxY = std::max(maxY, M * mid);
+    }
+    L.bstat0 = b.take((long)cfg.init_ch * 16);
+    L.part = b.take(max_part * 2);                     // x2: backward partials carry 3 doubles per channel
+    L.tabs = b.take((long)tab_floats() * 4);
+    L.F = b.take((long)n * Cf * 4);
+    L.Z = b.take((long)n * cfg.out_dim * 4);
+    L.head_stat = b.take((long)cfg.out_dim * 8);
+    L.wk = b.take(wk_bytes());
+    L.fwd_end = b.off;
+    if (bwd) layout_bwd(n, b.off, maxY, L);
+    else L.total = b.off;
+}
+
+long DenseNetPlan::tab_floats() const {
+    // (scale, shift) per BN layer, channel count rounded to 8
+    long t = 0;
+    auto add = [&](const BnSlots& s) { t += 2 * round_up(s.C, 8); };
+    add(n0);
+    for (const auto& bg : blocks) {
+        for (const auto& ls : bg.layers) { add(ls.n1); add(ls.n2); }
+        if (bg.has_trans) add(bg.tn);
+    }
+    add(nf);
+    return t;
+}
+
+// offsets (in floats) of the table of BN layer `s` inside the tabs region: sc at off, sh at off + round_up(C, 8)
+long DenseNetPlan::tab_off(const BnSlots& s) const {
+    long t = 0;
+    bool found = false;
+    auto add = [&](const BnSlots& q) {
+        if (found) return;
+        if (q.id == s.id) { found = true; return; }
+        t += 2 * round_up(q.C, 8);
+    };
+    add(n0);
+    for (const auto& bg : blocks) {
+        for (const auto& ls : bg.layers) { add(ls.n1); add(ls.n2); }
+        if (bg.has_trans) add(bg.tn);
+    }
+    add(nf);
+    return t;
+}
+
+long DenseNetPlan::wk_bytes() const {
+    long t = 0;
+    for (const auto& w : wk_list()) t += round_up((long)w.rows * w.Kp * esz, 256);
+    return t;
+}
+
+// every conv weight in kernel layout; the order defines the offsets in the wk region
+std::vector<WkEntry> DenseNetPlan::wk_list() const {
+    std::vector<WkEntry> v;
+    const int mid = cfg.bn_size * cfg.growth, g = cfg.growth;
+    long off = 0;
+    auto add = [&](int slot, int N, int Cin, int taps, int transpose) {
+        WkEntry e;
+        e.slot = slot; e.N = N; e.Cin = Cin; e.taps = taps; e.transpose = transpose;
+        e.rows = transpose ? Cin : N;
+        e.Kp = (int)round_up((long)taps * (transpose ? N : Cin), 32);
+        e.off = off;
+        off += round_up((long)e.rows * e.Kp * esz, 256);
+        v.push_back(e);
+    };
+    add(s_w0, cfg.init_ch, cfg.in_ch, 49, 0);
+    for (const auto& bg : blocks) {
+        for (const auto& ls : bg.layers) {
+            add(ls.w1, mid, ls.cin, 1, 0);
+            add(ls.w2, g, mid, 9, 0);
+            add(ls.w1, mid, ls.cin, 1, 1);     // dgrad layouts
+            add(ls.w2, g, mid, 9, 1);
+        }
+        if (bg.has_trans) { add(bg.tw, bg.Ctot / 2, bg.Ctot, 1, 0); add(bg.tw, bg.Ctot / 2, bg.Ctot, 1, 1); }
+    }
+    return v;
+}
+
+const WkEntry& DenseNetPlan::wk_find(int slot, int transpose) const {
+    for (const auto& e : wk_cache)
+        if (e.slot == slot && e.transpose == transpose) return e;
+    fprintf(stderr, "tcvn: wk_find miss\n");
+    abort();
+}
+
+int DenseNetPlan::bind(void* const* d, void* const* g) {
+    for (size_t i = 0; i < slots.size(); ++i) {
+        data[i] = reinterpret_cast<float*>(d[i]);
+        grad[i] = g ? reinterpret_cast<float*>(g[i]) : nullptr;
+        if (slots[i].kind != TCVN_SLOT_COUNTER && data[i] == nullptr) {
+            fprintf(stderr, "tcvn: slot %s unbound\n", slots[i].name.c_str());
+            return -10;
+        }
+    }
+    wk_cache = wk_list();
+    bound = true;
+    desc_ws = nullptr;   // device descriptor tables are rebuilt on the next forward
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Tab { float* sc; float* sh; };
+}
+
+int DenseNetPlan::upload_descs(char* ws, const Layout& L, hipStream_t st) {
+    // Pack descriptors (weights -> kernel layout) and eval-mode BN descriptors live in a small device table that
+    // depends on the workspace address; rebuilt only when the workspace base or the bindings change.
+    if (desc_ws == ws && desc_total == L.total) return 0;
+    std::vector<PackDesc> pd;
+    for (const auto& e : wk_cache) {
+        PackDesc d;
+        d.src = data[e.slot]; d.dst = ws + L.wk + e.off; d.N = e.N; d.Cin = e.Cin; d.taps = e.taps; d.Kp = e.Kp;
+        d.transpose = e.transpose;
+        pd.push_back(d);
+    }
+    std::vector<BnEvalDesc> bd;
+    float* tabs = reinterpret_cast<float*>(ws + L.tabs);
+    auto addbn = [&](const BnSlots& s) {
+        BnEvalDesc d;
+        d.gamma = data[s.w]; d.beta = data[s.b]; d.rm = data[s.rm]; d.rv = data[s.rv];
+        d.sc = tabs + tab_off(s); d.sh = d.sc + round_up(s.C, 8); d.C = s.C;
+        bd.push_back(d);
+    };
+    addbn(n0);
+    for (const auto& bg : blocks) {
+        for (const auto& ls : bg.layers) { addbn(ls.n1); addbn(ls.n2); }
+        if (bg.has_trans) addbn(bg.tn);
+    }
+    addbn(nf);
+    n_pack = (int)pd.size(); n_bneval = (int)bd.size();
+    const size_t bytes = pd.size() * sizeof(PackDesc) + bd.size() * sizeof(BnEvalDesc);
+    if (bytes > desc_cap) {
+        if (d_desc) TCVN_CHECK(hipFree(d_desc));
+        TCVN_CHECK(hipMalloc(&d_desc, bytes));
+        desc_cap = bytes;
+    }
+    h_desc.resize(bytes);
+    memcpy(h_desc.data(), pd.data(), pd.size() * sizeof(PackDesc));
+    memcpy(h_desc.data() + pd.size() * sizeof(PackDesc), bd.data(), bd.size() * sizeof(BnEvalDesc));
+    TCVN_CHECK(hipMemcpyAsync(d_desc, h_desc.data(), bytes, hipMemcpyHostToDevice, st));
+    desc_ws = ws; desc_total = L.total;
+    return 0;
+}
+
+int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, long nnz, int log_pixels, float noise_std,
+                          float* out, long out_ld, char* ws, long ws_bytes, int train, uint64_t seed, hipStream_t st) {
+    if (!bound) return -11;
+    if (n <= 0) return 0;
+    Layout L;
+    layout(n, train != 0, L);
+    if (ws_bytes < L.total) { fprintf(stderr, "tcvn: densenet workspace too small (%ld < %ld)\n", ws_bytes, L.total); return -12; }
+    int rc;
+    if ((rc = upload_descs(ws, L, st))) return rc;
+    const int mode = cfg.mode, g = cfg.growth, mid = cfg.bn_size * cfg.growth;
+    float* tabs = reinterpret_cast<float*>(ws + L.tabs);
+    auto tab = [&](const BnSlots& s) { Tab t; t.sc = tabs + tab_off(s); t.sh = t.sc + round_up(s.C, 8); return t; };
+    double* part = reinterpret_cast<double*>(ws + L.part);
+    const PackDesc* d_pack = reinterpret_cast<const PackDesc*>(d_desc);
+    const BnEvalDesc* d_bn = reinterpret_cast<const BnEvalDesc*>(d_desc + n_pack * sizeof(PackDesc));
+
+    // weights -> kernel layout (fp32 -> T); eval: all BN tables from the running statistics in one launch
+    if ((rc = pack_weights(d_pack, n_pack, mode, st))) return rc;
+    if (!train && (rc = bn_eval_tables(d_bn, n_bneval, kEps, st))) return rc;
+
+    auto link = [&](const BnSlots& s, const double* prt, int nblk, int part_ld, int c_new0, int n_new, double* bstat,
+                    long count) -> int {
+        if (!train) return 0;
+        BnLinkArgs a;
+        a.part = prt; a.nblk = nblk; a.part_ld = part_ld; a.c_new0 = c_new0; a.n_new = n_new; a.bstat = bstat;
+        a.count = count; a.C = s.C; a.gamma = data[s.w]; a.beta = data[s.b];
+        a.running_mean = data[s.rm]; a.running_var = data[s.rv];
+        Tab t = tab(s); a.sc = t.sc; a.sh = t.sh; a.train = 1; a.eps = kEps; a.momentum = kMom;
+        return bn_link(a, st);
+    };
+
+    // ---- pixel scatter + stem ----
+    TCVN_CHECK(hipMemsetAsync(ws + L.img, 0, (size_t)n * cfg.H * cfg.W * cfg.in_ch * esz, st));
+    {
+        ScatterArgs a{mode, coords, values, nnz, n, ws + L.img, cfg.H, cfg.W, cfg.in_ch, log_pixels, train ? noise_std : 0.f, seed};
+        if ((rc = scatter_pixels(a, st))) return rc;
+    }
+    const long M0 = (long)n * Hc * Wc;
+    {
+        const WkEntry& e = wk_find(s_w0, 0);
+        ConvFwdArgs a{};
+        a.mode = mode; a.amode = A_STEM; a.A = ws + L.img; a.lda = cfg.in_ch; a.M = (int)M0; a.N = cfg.init_ch;
+        a.K = 49 * cfg.in_ch; a.Kp = e.Kp; a.C = cfg.in_ch; a.H = Hc; a.W = Wc; a.Hin = cfg.H; a.Win = cfg.W;
+        a.Wk = ws + L.wk + e.off; a.bias = data[s_b0]; a.Out = ws + L.c0; a.ldo = cfg.init_ch; a.n_off = 0;
+        a.part = train ? part : nullptr; a.nblk = conv_fwd_grid((int)M0);
+        if ((rc = conv_fwd(a, st))) return rc;
+        if ((rc = link(n0, part, a.nblk, cfg.init_ch, 0, cfg.init_ch, reinterpret_cast<double*>(ws + L.bstat0), M0))) return rc;
+    }
+    {
+        const BlockGeom& b0 = blocks[0];
+        Tab t = tab(n0);
+        Pool0Args a{mode, ws + L.c0, n, Hc, Wc, cfg.init_ch, t.sc, t.sh, data[s_a0], ws + L.D[0], b0.ld, b0.H, b0.W,
+                    train ? part : nullptr, pool0_grid(n, b0.H, b0.W)};
+        if ((rc = pool0_fwd(a, st))) return rc;
+    }
+    // statistics of the block's initial channels are described by (prev_part_nblk, prev_part_ld)
+    int init_nblk = pool0_grid(n, blocks[0].H, blocks[0].W), init_ld = cfg.init_ch;
+
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        const BlockGeom& bg = blocks[bi];
+        const long M = (long)n * bg.H * bg.W;
+        char* D = ws + L.D[bi];
+        double* bstatD = reinterpret_cast<double*>(ws + L.bstatD[bi]);
+        int new_c0 = 0, new_n = bg.C0, new_nblk = init_nblk, new_ld = init_ld;   // channels whose stats are fresh in `part`
+        for (int l = 0; l < bg.L; ++l) {
+            const LayerSlots& ls = bg.layers[l];
+            if ((rc = link(ls.n1, part, new_nblk, new_ld, new_c0, new_n, bstatD, M))) return rc;
+            {   // bottleneck 1x1: D[:, 0:cin] -> Y
+                const WkEntry& e = wk_find(ls.w1, 0);
+                Tab t = tab(ls.n1);
+                ConvFwdArgs a{};
+                a.mode = mode; a.amode = A_1X1; a.A = D; a.lda = bg.ld; a.M = (int)M; a.N = mid; a.K = ls.cin; a.Kp = e.Kp;
+                a.C = ls.cin; a.H = bg.H; a.W = bg.W; a.sc = t.sc; a.sh = t.sh; a.sl = data[ls.a1];
+                a.Wk = ws + L.wk + e.off; a.bias = data[ls.b1]; a.Out = ws + L.Y[bi][l]; a.ldo = mid; a.n_off = 0;
+                a.part = train ? part : nullptr; a.nblk = conv_fwd_grid((int)M);
+                if ((rc = conv_fwd(a, st))) return rc;
+                if ((rc = link(ls.n2, part, a.nblk, mid, 0, mid, reinterpret_cast<double*>(ws + L.bstatY[bi][l]), M))) return rc;
+            }
+            {   // 3x3: Y -> D[:, cin:cin+g]
+                const WkEntry& e = wk_find(ls.w2, 0);
+                Tab t = tab(ls.n2);
+                ConvFwdArgs a{};
+                a.mode = mode; a.amode = A_3X3; a.A = ws + L.Y[bi][l]; a.lda = mid; a.M = (int)M; a.N = g; a.K = 9 * mid;
+                a.Kp = e.Kp; a.C = mid; a.H = bg.H; a.W = bg.W; a.sc = t.sc; a.sh = t.sh; a.sl = data[ls.a2];
+                a.Wk = ws + L.wk + e.off; a.bias = data[ls.b2]; a.Out = D; a.ldo = bg.ld; a.n_off = ls.cin;
+                a.part = train ? part : nullptr; a.nblk = conv_fwd_grid((int)M);
+                a.drop_p = train ? cfg.dropout : 0.f; a.seed = seed; a.stream_id = (uint32_t)(bi * 64 + l + 1);
+                if ((rc = conv_fwd(a, st))) return rc;
+                new_c0 = ls.cin; new_n = g; new_nblk = a.nblk; new_ld = g;
+            }
+        }
+        if (bg.has_trans) {
+            const BlockGeom& nb = blocks[bi + 1];
+            if ((rc = link(bg.tn, part, new_nblk, new_ld, new_c0, new_n, bstatD, M))) return rc;
+            const WkEntry& e = wk_find(bg.tw, 0);
+            Tab t = tab(bg.tn);
+            const long Mn = (long)n * nb.H * nb.W;
+            ConvFwdArgs a{};
+            a.mode = mode; a.amode = A_1X1_POOL; a.A = D; a.lda = bg.ld; a.M = (int)Mn; a.N = bg.Ctot / 2; a.K = bg.Ctot;
+            a.Kp = e.Kp; a.C = bg.Ctot; a.H = nb.H; a.W = nb.W; a.Hin = bg.H; a.Win = bg.W;
+            a.sc = t.sc; a.sh = t.sh; a.sl = data[bg.ta];
+            a.Wk = ws + L.wk + e.off; a.bias = data[bg.tb]; a.Out = ws + L.D[bi + 1]; a.ldo = nb.ld; a.n_off = 0;
+            a.part = train ? part : nullptr; a.nblk = conv_fwd_grid((int)Mn);
+            if ((rc = conv_fwd(a, st))) return rc;
+            init_nblk = a.nblk; init_ld = bg.Ctot / 2;
+        } else {
+            if ((rc = link(nf, part, new_nblk, new_ld, new_c0, new_n, bstatD, M))) return rc;
+            Tab t = tab(nf);
+            HeadPoolArgs a{mode, D, bg.ld, n, bg.H * bg.W, Cf, t.sc, t.sh, data[s_af], reinterpret_cast<float*>(ws + L.F)};
+            if ((rc = head_pool_fwd(a, st))) return rc;
+        }
+    }
+    // ---- output block: Linear(no bias) - BatchNorm1d - PReLU - Dropout (layers/dense_net.py:157-162) ----
+    float* F = reinterpret_cast<float*>(ws + L.F);
+    float* Z = reinterpret_cast<float*>(ws + L.Z);
+    if ((rc = linear_fwd(F, Cf, data[s_wl], nullptr, Z, cfg.out_dim, n, cfg.out_dim, Cf, st))) return rc;
+    float* hs = reinterpret_cast<float*>(ws + L.head_stat);
+    RowsBnArgs r{};
+    r.X = Z; r.ldx = cfg.out_dim; r.R = n; r.C = cfg.out_dim; r.gamma = data[nl.w]; r.beta = data[nl.b]; r.slope = data[s_al];
+    r.running_mean = data[nl.rm]; r.running_var = data[nl.rv]; r.Y = out; r.ldy = out_ld;
+    r.save_mean = hs; r.save_rstd = hs + cfg.out_dim; r.train = train; r.eps = kEps; r.momentum = kMom;
+    r.drop_p = train ? cfg.dropout : 0.f; r.seed = seed; r.stream_id = 0x4000u;
+    if ((rc = rows_bn_fwd(r, st))) return rc;
+    last_seed = seed; last_n = n;
+    return 0;
+}
+
+int DenseNetPlan::tap(int n, const char* name, long* off, int* tn, int* th, int* tw, int* tc, int* tld, int* tes) const {
+    Layout L;
+    layout(n, false, L);
+    std::string s(name);
+    *tn = n; *tes = esz;
+    if (s == "conv0") { *off = L.c0; *th = Hc; *tw = Wc; *tc = cfg.init_ch; *tld = cfg.init_ch; return 0; }
+    if (s == "condense") { *off = L.F; *th = 1; *tw = 1; *tc = Cf; *tld = Cf; *tes = 4; return 0; }
+    if (s.rfind("dense", 0) == 0) {
+        const int b = atoi(s.c_str() + 5) - 1;
+        if (b < 0 || b >= (int)blocks.size()) return -1;
+        *off = L.D[b]; *th = blocks[b].H; *tw = blocks[b].W; *tc = blocks[b].Ctot; *tld = blocks[b].ld;
+        return 0;
+    }
+    if (s.rfind("bottleneck", 0) == 0) {
+        int b = 0, l = 0;
+        if (sscanf(s.c_str(), "bottleneck%d.%d", &b, &l) != 2) return -1;
+        b -= 1;
+        if (b < 0 || b >= (int)blocks.size() || l < 0 || l >= blocks[b].L) return -1;
+        *off = L.Y[b][l]; *th = blocks[b].H; *tw = blocks[b].W; *tc = cfg.bn_size * cfg.growth; *tld = *tc;
+        return 0;
+    }
+    return -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+struct tcvn_densenet { DenseNetPlan plan; explicit tcvn_densenet(const tcvn_densenet_cfg& c) : plan(c) {} };
+
+extern "C" {
+
+int tcvn_version(void) { return 1; }
+
+int tcvn_densenet_create(const tcvn_densenet_cfg* cfg, tcvn_densenet** out) {
+    if (!cfg || !out || cfg->n_blocks < 1 || cfg->n_blocks > 8) return -1;
+    if (cfg->mode != TCVN_MODE_F32 && cfg->mode != TCVN_MODE_BF16) return -1;
+    *out = new tcvn_densenet(*cfg);
+    return 0;
+}
+void tcvn_densenet_destroy(tcvn_densenet* p) { delete p; }
+int tcvn_densenet_num_slots(const tcvn_densenet* p) { return (int)p->plan.slots.size(); }
+int tcvn_densenet_slot(const tcvn_densenet* p, int i, char* name, int cap, int64_t* numel, int* kind) {
+    if (i < 0 || i >= (int)p->plan.slots.size()) return -1;
+    const auto& s = p->plan.slots[i];
+    if (name && cap > 0) { strncpy(name, s.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (numel) *numel = s.numel;
+    if (kind) *kind = s.kind;
+    return 0;
+}
+int tcvn_densenet_bind(tcvn_densenet* p, void* const* data, void* const* grad) { return p->plan.bind(data, grad); }
+int64_t tcvn_densenet_workspace_bytes(const tcvn_densenet* p, int n_img, int with_backward) {
+    Layout L;
+    p->plan.layout(n_img, with_backward != 0, L);
+    return L.total;
+}
+int tcvn_densenet_forward(tcvn_densenet* p, int n_img, const int32_t* coords, const float* values, int64_t nnz, int log_pixels,
+                          float noise_std, float* out, int64_t out_ld, void* ws, int64_t ws_bytes, int train, uint64_t seed,
+                          void* stream) {
+    return p->plan.forward(n_img, coords, values, nnz, log_pixels, noise_std, out, out_ld, reinterpret_cast<char*>(ws), ws_bytes,
+                           train, seed, reinterpret_cast<hipStream_t>(stream));
+}
+int tcvn_densenet_backward(tcvn_densenet* p, int n_img, const float* d_out, int64_t d_out_ld, void* ws, int64_t ws_bytes,
+                           void* stream) {
+    return p->plan.backward(n_img, d_out, d_out_ld, reinterpret_cast<char*>(ws), ws_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+int tcvn_densenet_tap(const tcvn_densenet* p, int n_img, const char* name, int64_t* byte_off, int* n, int* h, int* w, int* c,
+                      int* ld, int* elem_bytes) {
+    long off = 0;
+    int rc = p->plan.tap(n_img, name, &off, n, h, w, c, ld, elem_bytes);
+    *byte_off = off;
+    return rc;
+}
+
+}  // extern "C"

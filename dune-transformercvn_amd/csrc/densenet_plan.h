@@ -1,0 +1,65 @@
+// DenseNet plan: slot table, geometry, workspace layout, forward/backward drivers.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/tcvn_hip.h"
+#include "tcvn_common.h"
+
+namespace tcvn {
+
+struct Slot { std::string name; long numel; int kind; };
+struct BnSlots { int w = -1, b = -1, rm = -1, rv = -1, nbt = -1, C = 0, id = -1; };
+struct LayerSlots { BnSlots n1, n2; int a1, w1, b1, a2, w2, b2, cin; };
+struct BlockGeom {
+    int H, W, C0, L, Ctot, ld;
+    std::vector<LayerSlots> layers;
+    bool has_trans = false;
+    BnSlots tn; int ta = -1, tw = -1, tb = -1;
+};
+struct WkEntry { int slot, N, Cin, taps, transpose, rows, Kp; long off; };
+
+struct Layout {
+    long img, c0, bstat0, part, tabs, F, Z, head_stat, wk, fwd_end, total;
+    std::vector<long> D, bstatD;
+    std::vector<std::vector<long>> Y, bstatY;
+    // backward
+    long du, du0, pq0, pqY, gwk, bpart, dF, dZ;
+    std::vector<long> G, pqD;
+};
+
+struct DenseNetPlan {
+    tcvn_densenet_cfg cfg;
+    int esz, Hc, Wc, Cf, n_bn = 0;
+    std::vector<Slot> slots;
+    std::vector<float*> data, grad;
+    std::vector<BlockGeom> blocks;
+    int s_w0, s_b0, s_a0, s_af, s_wl, s_al;
+    BnSlots n0, nf, nl;
+    std::vector<WkEntry> wk_cache;
+    bool bound = false;
+    // device descriptor table (pack + eval BN descriptors)
+    char* d_desc = nullptr; size_t desc_cap = 0; std::vector<char> h_desc;
+    char* desc_ws = nullptr; long desc_total = 0; int n_pack = 0, n_bneval = 0;
+    uint64_t last_seed = 0; int last_n = 0;
+
+    explicit DenseNetPlan(const tcvn_densenet_cfg& c);
+    ~DenseNetPlan();
+    int add_slot(const std::string& name, long numel, int kind);
+    BnSlots add_bn(const std::string& p, int c);
+    void layout(int n, bool bwd, Layout& L) const;
+    void layout_bwd(int n, long start, long maxY, Layout& L) const;
+    long tab_floats() const;
+    long tab_off(const BnSlots& s) const;
+    long wk_bytes() const;
+    std::vector<WkEntry> wk_list() const;
+    const WkEntry& wk_find(int slot, int transpose) const;
+    int bind(void* const* d, void* const* g);
+    int upload_descs(char* ws, const Layout& L, hipStream_t st);
+    int forward(int n, const int32_t* coords, const float* values, long nnz, int log_pixels, float noise_std, float* out,
+                long out_ld, char* ws, long ws_bytes, int train, uint64_t seed, hipStream_t st);
+    int backward(int n, const float* d_out, long d_out_ld, char* ws, long ws_bytes, hipStream_t st);
+    int tap(int n, const char* name, long* off, int* tn, int* th, int* tw, int* tc, int* tld, int* tes) const;
+};
+
+}  // namespace tcvn

@@ -1,0 +1,226 @@
+// HBM-bound helper kernels of the DenseNet forward path: pixel scatter, BatchNorm statistics plumbing,
+// the fused BN+PReLU+AvgPool stem tail, the global-average head and the weight re-layout.
+#include "tcvn_ops.h"
+
+namespace tcvn {
+
+namespace {
+
+// ---- BatchNorm link: finalize producer statistics, build the consumer table, update running stats -------------
+// Reference semantics: torch.nn.BatchNorm2d in training mode (biased batch variance for normalisation, unbiased for
+// running_var, momentum 0.1), as instantiated at layers/dense_net.py:19,30,85,119,147.
+__global__ __launch_bounds__(256) void k_bn_link(const BnLinkArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= a.C) return;
+    double mean, var;
+    if (a.train) {
+        if (c >= a.c_new0 && c < a.c_new0 + a.n_new) {
+            double s1 = 0, s2 = 0;
+            for (int b = lane; b < a.nblk; b += 64) {
+                const double* p = a.part + ((long)b * a.part_ld + (c - a.c_new0)) * 2;
+                s1 += p[0]; s2 += p[1];
+            }
+            s1 = wave_sum(s1); s2 = wave_sum(s2);
+            mean = s1 / (double)a.count;
+            var = s2 / (double)a.count - mean * mean;
+            if (var < 0) var = 0;
+            if (lane == 0) { a.bstat[c * 2] = mean; a.bstat[c * 2 + 1] = var; }
+        } else {
+            mean = a.bstat[c * 2]; var = a.bstat[c * 2 + 1];
+        }
+    } else {
+        mean = a.running_mean[c]; var = a.running_var[c];
+    }
+    if (lane == 0) {
+        const float r = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float sc = a.gamma[c] * r;
+        a.sc[c] = sc;
+        a.sh[c] = a.beta[c] - (float)mean * sc;
+        if (a.train && a.running_mean != nullptr) {
+            const double unb = a.count > 1 ? var * (double)a.count / (double)(a.count - 1) : var;
+            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+        }
+    }
+}
+
+__global__ void k_bn_eval_tables(const BnEvalDesc* d, float eps) {
+    const BnEvalDesc e = d[blockIdx.x];
+    for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+        const float r = 1.0f / sqrtf(e.rv[c] + eps);
+        const float sc = e.gamma[c] * r;
+        e.sc[c] = sc;
+        e.sh[c] = e.beta[c] - e.rm[c] * sc;
+    }
+}
+
+// ---- COO pixel list -> dense NHWC map (reference: trainers/neutrino_full_dense_trainer.py:15-24, :46-67) ---------
+// The map must be zero-filled beforehand.  Duplicate coordinates are last-writer-wins like the reference's
+// non-accumulating indexed `+=`.
+template <typename T>
+__global__ void k_scatter(const ScatterArgs a) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nnz) return;
+    const int img = a.coords[i * 3], y = a.coords[i * 3 + 1], x = a.coords[i * 3 + 2];
+    if (img < 0 || img >= a.n_img || y < 0 || y >= a.H || x < 0 || x >= a.W) return;
+    T* o = reinterpret_cast<T*>(a.img) + (((long)img * a.H + y) * a.W + x) * a.Cpix;
+    for (int c = 0; c < a.Cpix; ++c) {
+        float v = a.values[i * a.Cpix + c];
+        v = a.log_pixels ? logf(v + 1.f) : v / 255.0f;
+        if (a.noise_std != 0.f) {             // v * (1 + N(0,1) * std): Box-Muller on two counter-based uniforms
+            const float u1 = fmaxf(rng_uniform(a.seed, 0x6e6f6973u, (uint64_t)(i * a.Cpix + c) * 2), 1e-7f);
+            const float u2 = rng_uniform(a.seed, 0x6e6f6973u, (uint64_t)(i * a.Cpix + c) * 2 + 1);
+            v *= 1.f + a.noise_std * sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
+        }
+        o[c] = from_f<T>(v);
+    }
+}
+
+// ---- stem tail: BN + PReLU + AvgPool(3, stride 2) (layers/dense_net.py:119-121) ----------------------------------
+constexpr int POOL_CJ = 4;   // up to 256 channels
+template <typename T>
+__global__ __launch_bounds__(256) void k_pool0(const Pool0Args a) {
+    __shared__ double red[4][64 * POOL_CJ][2];
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    T* O = reinterpret_cast<T*>(a.Out);
+    double s1[POOL_CJ], s2[POOL_CJ];
+    float sc[POOL_CJ], sh[POOL_CJ], sl[POOL_CJ];
+#pragma unroll
+    for (int j = 0; j < POOL_CJ; ++j) {
+        s1[j] = 0; s2[j] = 0;
+        const int c = cl + 64 * j;
+        sc[j] = c < a.C ? a.sc[c] : 0.f; sh[j] = c < a.C ? a.sh[c] : 0.f; sl[j] = c < a.C ? a.sl[c] : 0.f;
+    }
+    const long npix = (long)a.n_img * a.Ho * a.Wo;
+    for (long p = (long)blockIdx.x * 4 + pg; p < npix; p += (long)gridDim.x * 4) {
+        const int wo = (int)(p % a.Wo);
+        const int ho = (int)((p / a.Wo) % a.Ho);
+        const long img = p / ((long)a.Wo * a.Ho);
+        const T* base = X + ((img * a.Hin + 2 * ho) * a.Win + 2 * wo) * a.C;
+#pragma unroll
+        for (int j = 0; j < POOL_CJ; ++j) {
+            const int c = cl + 64 * j;
+            if (c < a.C) {
+                float acc = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        acc += prelu(fmaf(to_f<T>(base[((long)dy * a.Win + dx) * a.C + c]), sc[j], sh[j]), sl[j]);
+                const T o = from_f<T>(acc * (1.0f / 9.0f));
+                O[p * a.ldo + c] = o;
+                const double v = (double)to_f<T>(o);
+                s1[j] += v; s2[j] += v * v;
+            }
+        }
+    }
+    if (a.part == nullptr) return;
+#pragma unroll
+    for (int j = 0; j < POOL_CJ; ++j) { red[pg][cl + 64 * j][0] = s1[j]; red[pg][cl + 64 * j][1] = s2[j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        double x = 0, y = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { x += red[g][c][0]; y += red[g][c][1]; }
+        a.part[((long)blockIdx.x * a.C + c) * 2] = x;
+        a.part[((long)blockIdx.x * a.C + c) * 2 + 1] = y;
+    }
+}
+
+// ---- head: final BN + PReLU + global average (layers/dense_net.py:147-154) ----------------------------------------
+template <typename T>
+__global__ void k_head_pool(const HeadPoolArgs a) {
+    const int img = blockIdx.x;
+    const T* X = reinterpret_cast<const T*>(a.X) + (long)img * a.HW * a.ldx;
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        const float sc = a.sc[c], sh = a.sh[c], sl = a.sl[c];
+        float acc = 0.f;
+        for (int p = 0; p < a.HW; ++p) acc += prelu(fmaf(to_f<T>(X[(long)p * a.ldx + c]), sc, sh), sl);
+        a.F[(long)img * a.C + c] = acc / (float)a.HW;
+    }
+}
+
+// ---- weight re-layout -----------------------------------------------------------------------------------------------
+// transpose == 0 : dst[n][tap*Cin + c] = src[n][c][tap]                       (forward / wgrad operand layout)
+// transpose == 1 : dst[c][tap*N + n]   = src[n][c][tap]   (dgrad operand: rows = input channel, k = (tap, out ch))
+template <typename T>
+__global__ void k_pack(const PackDesc* descs) {
+    const PackDesc d = descs[blockIdx.y];
+    T* dst = reinterpret_cast<T*>(d.dst);
+    const int rows = d.transpose ? d.Cin : d.N;
+    const long total = (long)rows * d.Kp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / d.Kp), k = (int)(i % d.Kp);
+        float v = 0.f;
+        if (!d.transpose) {
+            if (k < d.taps * d.Cin) {
+                const int tap = k / d.Cin, c = k % d.Cin;
+                v = d.src[((long)r * d.Cin + c) * d.taps + tap];
+            }
+        } else {
+            if (k < d.taps * d.N) {
+                const int tap = k / d.N, n = k % d.N;
+                v = d.src[((long)n * d.Cin + r) * d.taps + tap];
+            }
+        }
+        dst[i] = from_f<T>(v);
+    }
+}
+
+}  // namespace
+
+int bn_link(const BnLinkArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_link, dim3(cdiv(a.C, 4)), dim3(256), 0, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_eval_tables(const BnEvalDesc* d_descs, int n, float eps, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_bn_eval_tables, dim3(n), dim3(256), 0, st, d_descs, eps);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int scatter_pixels(const ScatterArgs& a, hipStream_t st) {
+    if (a.nnz <= 0) return 0;
+    if (a.mode == MODE_F32) hipLaunchKernelGGL(k_scatter<float>, dim3(cdiv(a.nnz, 256)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_scatter<bf16>, dim3(cdiv(a.nnz, 256)), dim3(256), 0, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int pool0_grid(int n_img, int Ho, int Wo) {
+    const long npix = (long)n_img * Ho * Wo;
+    const long g = (npix + 3) / 4;
+    return (int)(g < 1024 ? g : 1024);
+}
+
+int pool0_fwd(const Pool0Args& a, hipStream_t st) {
+    if (a.C > 64 * POOL_CJ) { fprintf(stderr, "tcvn: pool0 supports up to %d channels\n", 64 * POOL_CJ); return -2; }
+    const int gx = pool0_grid(a.n_img, a.Ho, a.Wo);
+    if (a.part != nullptr && a.nblk != gx) { fprintf(stderr, "tcvn: pool0 nblk mismatch\n"); return -3; }
+    if (a.mode == MODE_F32) hipLaunchKernelGGL(k_pool0<float>, dim3(gx), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_pool0<bf16>, dim3(gx), dim3(256), 0, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int head_pool_fwd(const HeadPoolArgs& a, hipStream_t st) {
+    if (a.mode == MODE_F32) hipLaunchKernelGGL(k_head_pool<float>, dim3(a.n_img), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_head_pool<bf16>, dim3(a.n_img), dim3(256), 0, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int pack_weights(const PackDesc* d_descs, int n, int mode, hipStream_t st) {
+    if (n <= 0) return 0;
+    if (mode == MODE_F32) hipLaunchKernelGGL(k_pack<float>, dim3(32, n), dim3(256), 0, st, d_descs);
+    else hipLaunchKernelGGL(k_pack<bf16>, dim3(32, n), dim3(256), 0, st, d_descs);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace tcvn

@@ -1,0 +1,115 @@
+// Common device/host helpers for the TransformerCVN gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace tcvn {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+
+typedef unsigned short bf16;   // storage type for bf16 activations / weights
+
+enum { MODE_F32 = 0, MODE_BF16 = 1 };
+
+__device__ __forceinline__ float bf2f(bf16 v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16 f2bf(float f) {          // round-to-nearest-even, NaN preserved
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16)((u >> 16) | 0x40);
+    return (bf16)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return f2bf(v); }
+// value as the consumer will see it after storage rounding
+template <typename T> __device__ __forceinline__ float round_to(float v) { return to_f<T>(from_f<T>(v)); }
+
+__device__ __forceinline__ float prelu(float u, float a) { return u > 0.f ? u : a * u; }
+
+// load 8 consecutive elements as float (vector path requires 16B/32B alignment)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float v[8]) {
+    const u16x8 a = *reinterpret_cast<const u16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = bf2f(a[j]);
+}
+template <typename T> __device__ __forceinline__ void load8_guard(const T* p, int n, float v[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = j < n ? to_f<T>(p[j]) : 0.f;
+}
+
+// counter-based RNG (Philox-4x32-10) for dropout masks and pixel noise: reproducible in backward
+__device__ __forceinline__ uint4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+// one uniform in [0,1) per (stream id, element index)
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint32_t stream, uint64_t idx) {
+    const uint4 r = philox4((uint32_t)(idx >> 2), (uint32_t)(idx >> 34), stream, 0x5443564eu, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
+    return (w >> 8) * (1.0f / 16777216.0f);
+}
+// dropout keep-scale for element idx: 0 or 1/(1-p)
+__device__ __forceinline__ float drop_scale(float p, uint64_t seed, uint32_t stream, uint64_t idx) {
+    if (p <= 0.f) return 1.f;
+    return rng_uniform(seed, stream, idx) >= p ? 1.f / (1.f - p) : 0.f;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+#define TCVN_CHECK(expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "tcvn: %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return (int)e_;                                                                \
+        }                                                                                  \
+    } while (0)
+
+#define TCVN_LAUNCH_CHECK()                                                                \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "tcvn: launch failed at %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return (int)e_;                                                                \
+        }                                                                                  \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+}  // namespace tcvn

@@ -1,0 +1,79 @@
+// Internal host-side launch interface of the gfx950 kernels (the public C-ABI in include/tcvn_hip.h wraps these).
+#pragma once
+#include "tcvn_common.h"
+
+namespace tcvn {
+
+enum AMode { A_1X1 = 0, A_1X1_POOL = 1, A_3X3 = 2, A_STEM = 3 };
+
+// ---------------------------------------------------------------------------------------------------------
+// Forward convolution as an implicit GEMM:  Out[m][n_off+n] = sum_k a(m,k) * Wk[n][k] + bias[n]
+//   a(m,k) is generated from the NHWC input with the producer-side BatchNorm + PReLU folded into the load:
+//   A_1X1      a = f_k(X[m][k])                                   f_c(x) = prelu(x*sc[c] + sh[c], sl[c])
+//   A_1X1_POOL a = 1/4 sum_{2x2} f_k(X[(img,2ho+dy,2wo+dx)][k])   (avg-pool commuted in front of the 1x1 conv)
+//   A_3X3      k = tap*C + c ; a = inside ? f_c(X[m + (ky-1)*W + (kx-1)][c]) : 0
+//   A_STEM     k = tap*3 + c ; 7x7 stride 2 pad 3 on the raw image, no transform
+// Optional epilogue: dropout, per-channel (sum, sum of squares) partials for the consumer BatchNorm.
+// ---------------------------------------------------------------------------------------------------------
+struct ConvFwdArgs {
+    int mode, amode;
+    const void* A; long lda;
+    int M, N, K, Kp;
+    int C, H, W, Hin, Win;
+    const float *sc, *sh, *sl;
+    const void* Wk; const float* bias;
+    void* Out; long ldo; int n_off;
+    double* part; int nblk;          // [nblk][N][2]; nblk = grid.x
+    float drop_p; uint64_t seed; uint32_t stream_id;
+};
+int conv_fwd(const ConvFwdArgs& a, hipStream_t st);
+int conv_fwd_grid(int M);            // number of M-blocks (== nblk) the launcher will use for M rows
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm plumbing
+// ---------------------------------------------------------------------------------------------------------
+// Reduce the producer's stat partials of channels [c_new0, c_new0+n_new) into bstat (mean, biased var) and build
+// the consumer's (scale, shift) table for channels [0, C); update the consumer's running statistics.
+struct BnLinkArgs {
+    const double* part; int nblk; int part_ld;   // partial row length (channels of the producing launch)
+    int c_new0, n_new;                           // channel window that `part` describes (may be empty)
+    double* bstat;                               // [Cbuf][2] (mean, biased var) of the buffer
+    long count;                                  // elements per channel
+    int C;                                       // consumer channels
+    const float *gamma, *beta;
+    float *running_mean, *running_var;           // updated when `train`
+    float *sc, *sh;                              // outputs [C]
+    int train; float eps, momentum;
+};
+int bn_link(const BnLinkArgs& a, hipStream_t st);
+
+// eval-mode tables for many BN layers in one launch
+struct BnEvalDesc { const float *gamma, *beta, *rm, *rv; float *sc, *sh; int C; };
+int bn_eval_tables(const BnEvalDesc* d_descs, int n, float eps, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------------------
+// Pixel-map scatter (COO -> dense NHWC), stem pooling, global pooling
+// ---------------------------------------------------------------------------------------------------------
+struct ScatterArgs {
+    int mode; const int* coords; const float* values; long nnz; int n_img;
+    void* img; int H, W, Cpix; int log_pixels; float noise_std; uint64_t seed;
+};
+int scatter_pixels(const ScatterArgs& a, hipStream_t st);
+
+// D[img,ho,wo,0:C] = avgpool3x3s2( prelu(bn(C0)) ), with stat partials for those channels
+struct Pool0Args {
+    int mode; const void* X; int n_img, Hin, Win, C; const float *sc, *sh, *sl;
+    void* Out; long ldo; int Ho, Wo; double* part; int nblk;
+};
+int pool0_fwd(const Pool0Args& a, hipStream_t st);
+int pool0_grid(int n_img, int Ho, int Wo);
+
+// F[img][c] = mean_hw prelu(bn(X[img,:,:,c]))   (fp32 output)
+struct HeadPoolArgs { int mode; const void* X; long ldx; int n_img, HW, C; const float *sc, *sh, *sl; float* F; };
+int head_pool_fwd(const HeadPoolArgs& a, hipStream_t st);
+
+// Weight re-layout: reference OIHW fp32 -> kernel layout [N][Kp] (k = tap*Cin + c), typed T, zero padded.
+struct PackDesc { const float* src; void* dst; int N, Cin, taps, Kp; int transpose; };
+int pack_weights(const PackDesc* d_descs, int n, int mode, hipStream_t st);
+
+}  // namespace tcvn

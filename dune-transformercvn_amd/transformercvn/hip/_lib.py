@@ -1,0 +1,80 @@
+"""ctypes binding of libtcvn_hip.so (the C ABI declared in include/tcvn_hip.h).
+
+The library is built in-tree by ``make -C dune-transformercvn_amd/csrc`` (or ``__graft_entry__.build()``).  There is no
+CPU fallback: if the shared object is missing or fails to load, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libtcvn_hip.so"))
+
+MODE_F32, MODE_BF16 = 0, 1
+SLOT_PARAM, SLOT_BUFFER, SLOT_COUNTER = 0, 1, 2
+
+
+class DenseNetCfg(C.Structure):
+    _fields_ = [("in_ch", C.c_int), ("out_dim", C.c_int), ("init_ch", C.c_int), ("growth", C.c_int), ("bn_size", C.c_int),
+                ("n_blocks", C.c_int), ("layers", C.c_int * 8), ("H", C.c_int), ("W", C.c_int), ("dropout", C.c_float),
+                ("mode", C.c_int)]
+
+
+class HeadCfg(C.Structure):
+    _fields_ = [("hidden_dim", C.c_int), ("heads", C.c_int), ("n_layers", C.c_int), ("in_dim", C.c_int),
+                ("event_classes", C.c_int), ("prong_classes", C.c_int), ("n_dec", C.c_int), ("dec_dims", C.c_int * 8),
+                ("dec_out_in", C.c_int), ("gelu", C.c_int), ("norm_first", C.c_int), ("dropout_modules", C.c_int),
+                ("dropout", C.c_float), ("gamma", C.c_float), ("event_weight", C.c_float)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"libtcvn_hip.so not found at {LIB_PATH}: build it with `make -C dune-transformercvn_amd/csrc -j8` "
+            "(hipcc, --offload-arch=gfx950). There is no CPU fallback for the TransformerCVN hot path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+    P = C.POINTER
+
+    def sig(name, res, *args):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+        return fn
+
+    sig("tcvn_version", i32)
+    sig("tcvn_densenet_create", i32, P(DenseNetCfg), P(vp))
+    sig("tcvn_densenet_destroy", None, vp)
+    sig("tcvn_densenet_num_slots", i32, vp)
+    sig("tcvn_densenet_slot", i32, vp, i32, C.c_char_p, i32, P(i64), P(i32))
+    sig("tcvn_densenet_bind", i32, vp, P(vp), P(vp))
+    sig("tcvn_densenet_workspace_bytes", i64, vp, i32, i32)
+    sig("tcvn_densenet_forward", i32, vp, i32, vp, vp, i64, i32, f32, vp, i64, vp, i64, i32, u64, vp)
+    sig("tcvn_densenet_backward", i32, vp, i32, vp, i64, vp, i64, vp)
+    sig("tcvn_densenet_tap", i32, vp, i32, C.c_char_p, P(i64), P(i32), P(i32), P(i32), P(i32), P(i32), P(i32))
+    sig("tcvn_head_create", i32, P(HeadCfg), P(vp))
+    sig("tcvn_head_destroy", None, vp)
+    sig("tcvn_head_num_slots", i32, vp)
+    sig("tcvn_head_slot", i32, vp, i32, C.c_char_p, i32, P(i64), P(i32))
+    sig("tcvn_head_bind", i32, vp, P(vp), P(vp))
+    sig("tcvn_head_workspace_bytes", i64, vp, i32, i32, i32)
+    sig("tcvn_head_forward", i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, i64, i32, u64, vp)
+    sig("tcvn_head_loss", i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp)
+    sig("tcvn_head_backward", i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, i64, vp)
+    return lib
+
+
+EXPORTS = [
+    "tcvn_version", "tcvn_densenet_create", "tcvn_densenet_destroy", "tcvn_densenet_num_slots", "tcvn_densenet_slot",
+    "tcvn_densenet_bind", "tcvn_densenet_workspace_bytes", "tcvn_densenet_forward", "tcvn_densenet_backward",
+    "tcvn_densenet_tap", "tcvn_head_create", "tcvn_head_destroy", "tcvn_head_num_slots", "tcvn_head_slot", "tcvn_head_bind",
+    "tcvn_head_workspace_bytes", "tcvn_head_forward", "tcvn_head_loss", "tcvn_head_backward",
+]
+
+lib = _load()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"libtcvn_hip: {what} failed with code {rc}")

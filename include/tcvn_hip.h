@@ -1,0 +1,125 @@
+/* tcvn_hip.h -- C ABI of libtcvn_hip.so: the MI355X (gfx950) implementation of the TransformerCVN hot path.
+ *
+ * The reference (ayankele/dune-transformercvn) has no native interface of its own: its hot path is the Python call
+ * chain NeutrinoFullDenseTrainer.forward -> NeutrinoDenseNetwork.forward -> torch ATen ops
+ * (transformercvn/network/trainers/neutrino_full_base_trainer.py:90-116, networks/neutrino_full_base_network.py:87-125,
+ * :166-188, layers/dense_net.py:8-167).  This header is the boundary a maintainer binds instead of those ATen calls
+ * (see INTEGRATION.md for the ctypes stub).  Plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ * named h_*; every function enqueues work on `stream` (a hipStream_t passed as void*) and returns 0 on success or a
+ * non-zero hipError_t / negative argument-error code.  No function allocates per call or synchronises the device;
+ * workspaces are supplied by the caller.
+ */
+#ifndef TCVN_HIP_H
+#define TCVN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCVN_MODE_F32 0  /* fp32 activations, v_mfma_f32_32x32x2_f32 : parity mode (1e-3 logit gate)      */
+#define TCVN_MODE_BF16 1 /* bf16 activations/weights, v_mfma_f32_32x32x16_bf16, fp32 accumulate/statistics */
+
+#define TCVN_SLOT_PARAM 0   /* float tensor with gradient            */
+#define TCVN_SLOT_BUFFER 1  /* float tensor without gradient (BN running statistics) */
+#define TCVN_SLOT_COUNTER 2 /* int64 scalar (num_batches_tracked); kept by the host, never read on the device */
+
+int tcvn_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * DenseNet embedder (replaces transformercvn/network/layers/dense_net.py:97-167 DenseNet.forward and its autograd)
+ * --------------------------------------------------------------------------------------------------------------- */
+typedef struct tcvn_densenet_cfg {
+    int in_ch;          /* pixel channels (3)                                   */
+    int out_dim;        /* embedding width (256 prong / 288 event)              */
+    int init_ch;        /* options.initial_pixel_dim                            */
+    int growth;         /* options.densenet_growth_rate                         */
+    int bn_size;        /* options.densenet_batch_norm_size                     */
+    int n_blocks;       /* len(options.densenet_structure) (<= 8)               */
+    int layers[8];      /* options.densenet_structure                           */
+    int H, W;           /* pixel map shape (400, 280)                           */
+    float dropout;      /* options.dropout                                      */
+    int mode;           /* TCVN_MODE_*                                          */
+} tcvn_densenet_cfg;
+
+typedef struct tcvn_densenet tcvn_densenet; /* opaque plan */
+
+int tcvn_densenet_create(const tcvn_densenet_cfg* cfg, tcvn_densenet** out);
+void tcvn_densenet_destroy(tcvn_densenet* p);
+
+/* Parameter slots in reference state_dict order; names are relative to the DenseNet module
+ * ("features.conv0.weight", ..., "output_block.relu.weight"). */
+int tcvn_densenet_num_slots(const tcvn_densenet* p);
+int tcvn_densenet_slot(const tcvn_densenet* p, int i, char* name, int name_cap, int64_t* numel, int* kind);
+/* data[i]: device pointer of slot i (fp32, reference layout: conv OIHW); grad[i]: fp32 gradient of the same shape
+ * (ignored for buffers/counters; may be NULL for inference-only use). */
+int tcvn_densenet_bind(tcvn_densenet* p, void* const* data, void* const* grad);
+
+int64_t tcvn_densenet_workspace_bytes(const tcvn_densenet* p, int n_img, int with_backward);
+
+/* Forward over n_img sparse pixel maps.
+ *   coords [nnz,3] int32 (image, y, x), values [nnz, in_ch] fp32 raw pixel values (reference:
+ *   trainers/neutrino_full_dense_trainer.py:15-24,46-67: v/255 or log(v+1), optional multiplicative noise, COO->dense).
+ *   out [n_img, out_dim] fp32 with row stride out_ld.
+ *   train != 0: batch statistics, running-stat update, dropout (seed) -- and the workspace keeps what backward needs. */
+int tcvn_densenet_forward(tcvn_densenet* p, int n_img, const int32_t* coords, const float* values, int64_t nnz,
+                          int log_pixels, float noise_std, float* out, int64_t out_ld, void* workspace,
+                          int64_t workspace_bytes, int train, uint64_t seed, void* stream);
+
+/* Backward of the last train-mode forward on the same workspace: d_out [n_img, out_dim] fp32 -> parameter gradients
+ * are ACCUMULATED into the bound grad pointers (zero them first). */
+int tcvn_densenet_backward(tcvn_densenet* p, int n_img, const float* d_out, int64_t d_out_ld, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
+/* Debug/validation taps into the workspace of the last forward: name in {"conv0","pool0","dense<i>","bottleneck<b>.<l>",
+ * "condense"}; returns element offset (bytes) and logical NHWC shape + channel stride. */
+int tcvn_densenet_tap(const tcvn_densenet* p, int n_img, const char* name, int64_t* byte_off, int* n, int* h, int* w,
+                      int* c, int* ld, int* elem_bytes);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Token path: combined embedding, transformer encoder, decoders, focal loss
+ * (networks/neutrino_full_base_network.py:99-125,184-188; layers/prong_custom_bert_encoder.py:57-75;
+ *  layers/prong_decoder.py:15-16; layers/prong_target_decoder.py:34-41; trainers/neutrino_full_base_trainer.py:148-177)
+ * --------------------------------------------------------------------------------------------------------------- */
+typedef struct tcvn_head_cfg {
+    int hidden_dim, heads, n_layers;       /* encoder: d_model, heads, layers; FFN width == hidden_dim (reference quirk) */
+    int in_dim;                            /* combined embedding input width (feat + pix + pos = 320)              */
+    int event_classes, prong_classes;
+    int n_dec; int dec_dims[8];            /* prong decoder widths after each hidden block (64,32,16,8)           */
+    int dec_out_in;                        /* in_features of prong_decoder.output_layer (reference quirk value)   */
+    int gelu;                              /* 1 = gelu, 0 = relu                                                   */
+    int norm_first;
+    int dropout_modules;                   /* 1 when options.dropout > 0 (shifts prong_decoder.hidden_layers idx)  */
+    float dropout; float gamma; float event_weight;
+} tcvn_head_cfg;
+
+typedef struct tcvn_head tcvn_head;
+int tcvn_head_create(const tcvn_head_cfg* cfg, tcvn_head** out);
+void tcvn_head_destroy(tcvn_head* p);
+int tcvn_head_num_slots(const tcvn_head* p);
+int tcvn_head_slot(const tcvn_head* p, int i, char* name, int name_cap, int64_t* numel, int* kind);
+int tcvn_head_bind(tcvn_head* p, void* const* data, void* const* grad);
+int64_t tcvn_head_workspace_bytes(const tcvn_head* p, int batch, int max_prongs, int n_prongs);
+
+/* rows [batch + n_prongs, in_dim] fp32: event rows first, then packed prong rows (already concatenated with the
+ * feature / position embeddings).  tok_row [batch, 1+max_prongs] int32: row index of each token or -1 for padding.
+ * Outputs: event_logits [batch, event_classes], prong_logits [batch, max_prongs, prong_classes]. */
+int tcvn_head_forward(tcvn_head* p, int batch, int max_prongs, int n_prongs, const float* rows, const int32_t* tok_row,
+                      float* event_logits, float* prong_logits, void* workspace, int64_t workspace_bytes, int train,
+                      uint64_t seed, void* stream);
+/* Softmax focal loss on the logits of the last forward (+ its gradient, kept in the workspace).
+ * event_targets [batch] int64, prong_targets [batch, max_prongs] int8 (-1 = padding).
+ * losses[3] (device, fp32) = {total, event, prong}; accs[2] = {event accuracy, prong accuracy}. */
+int tcvn_head_loss(tcvn_head* p, int batch, int max_prongs, const float* event_logits, const float* prong_logits,
+                   const int64_t* event_targets, const int8_t* prong_targets, float* losses, float* accs, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+/* Backward from the loss gradient in the workspace to d_rows [batch + n_prongs, in_dim]; parameter gradients are
+ * accumulated into the bound grad pointers. loss_scale multiplies d(total loss). */
+int tcvn_head_backward(tcvn_head* p, int batch, int max_prongs, int n_prongs, const float* rows, const int32_t* tok_row,
+                       float loss_scale, float* d_rows, void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCVN_HIP_H */
