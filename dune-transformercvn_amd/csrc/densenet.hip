@@ -93,6 +93,7 @@ DenseNetPlan::DenseNetPlan(const tcvn_densenet_cfg& c) : cfg(c) {
 
 DenseNetPlan::~DenseNetPlan() {
     if (d_desc) (void)hipFree(d_desc);
+    if (d_undesc) (void)hipFree(d_undesc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -219,6 +220,7 @@ int DenseNetPlan::bind(void* const* d, void* const* g) {
     wk_cache = wk_list();
     bound = true;
     desc_ws = nullptr;   // device descriptor tables are rebuilt on the next forward
+    undesc_ws = nullptr;
     return 0;
 }
 

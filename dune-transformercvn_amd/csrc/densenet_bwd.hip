@@ -1,5 +1,230 @@
-// DenseNet backward driver (placeholder until the backward kernels land).
+// DenseNet backward driver: reverse schedule of densenet.hip::forward on the same workspace.
+// Extra HBM state: G[b] (gradient accumulators shaped like the concat buffers), (P,Q) per channel, one bottleneck-sized
+// scratch DU, a conv0-sized scratch DU0, fp32 kernel-layout weight gradients (converted to OIHW at the end).
+#include <cstring>
+#include <vector>
+
 #include "densenet_plan.h"
+#include "tcvn_ops.h"
+#include "tcvn_rows.h"
+
 using namespace tcvn;
-void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const { (void)n; (void)maxY; L.total = start; }
-int DenseNetPlan::backward(int, const float*, long, char*, long, hipStream_t) { return -100; }
+
+namespace {
+constexpr float kEps = 1e-5f;
+struct Bump {
+    long off;
+    long take(long bytes) { long o = off; off += round_up(bytes, 256); return o; }
+};
+}  // namespace
+
+void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
+    Bump b{start};
+    const int mid = cfg.bn_size * cfg.growth;
+    L.G.clear(); L.pqD.clear();
+    // --- zeroed at the start of every backward: G, pqD, gwk (contiguous) ---
+    long bpart = (long)pool0_bwd_grid(n, Hc, Wc) * cfg.init_ch * 24;
+    bpart = std::max(bpart, (long)head_pool_bwd_grid(n) * Cf * 24);
+    for (const auto& bg : blocks) {
+        const long M = (long)n * bg.H * bg.W;
+        L.G.push_back(b.take(M * bg.ld * esz));
+        bpart = std::max(bpart, (long)conv_fwd_grid((int)M) * std::max(mid, bg.Ctot) * 24);
+    }
+    for (const auto& bg : blocks) L.pqD.push_back(b.take((long)bg.ld * 8));
+    long gw = 0;
+    for (const auto& e : wk_list())
+        if (!e.transpose) gw += round_up((long)e.N * e.Kp * 4, 256);
+    L.gwk = b.take(gw);
+    L.zero_end = b.off;
+    L.du = b.take(maxY * esz);
+    L.pqY = b.take((long)mid * 8);
+    L.du0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
+    L.pq0 = b.take((long)cfg.init_ch * 8);
+    L.bpart = b.take(bpart);
+    L.dF = b.take((long)n * Cf * 4);
+    L.dZ = b.take((long)n * cfg.out_dim * 4);
+    L.total = b.off;
+}
+
+int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, long ws_bytes, hipStream_t st) {
+    if (!bound) return -11;
+    if (n <= 0) return 0;
+    if (n != last_n) { fprintf(stderr, "tcvn: densenet backward without matching forward\n"); return -13; }
+    for (size_t i = 0; i < slots.size(); ++i)
+        if (slots[i].kind == TCVN_SLOT_PARAM && grad[i] == nullptr) { fprintf(stderr, "tcvn: grad of %s unbound\n", slots[i].name.c_str()); return -14; }
+    Layout L;
+    layout(n, true, L);
+    if (ws_bytes < L.total) return -12;
+    int rc;
+    const int mode = cfg.mode, g = cfg.growth, mid = cfg.bn_size * cfg.growth;
+    const uint64_t seed = last_seed;
+    float* tabs = reinterpret_cast<float*>(ws + L.tabs);
+    auto sc_of = [&](const BnSlots& s) { return tabs + tab_off(s); };
+    auto sh_of = [&](const BnSlots& s) { return tabs + tab_off(s) + round_up(s.C, 8); };
+    double* part = reinterpret_cast<double*>(ws + L.bpart);
+
+    // kernel-layout gradient offsets follow wk_list order (non-transposed entries only)
+    std::vector<long> gw_off(wk_cache.size(), -1);
+    {
+        long o = 0;
+        for (size_t i = 0; i < wk_cache.size(); ++i)
+            if (!wk_cache[i].transpose) { gw_off[i] = o; o += round_up((long)wk_cache[i].N * wk_cache[i].Kp * 4, 256); }
+    }
+    auto gw_of = [&](int slot) -> float* {
+        for (size_t i = 0; i < wk_cache.size(); ++i)
+            if (wk_cache[i].slot == slot && !wk_cache[i].transpose) return reinterpret_cast<float*>(ws + L.gwk + gw_off[i]);
+        return nullptr;
+    };
+    // device table of unpack descriptors (depends on ws)
+    if (undesc_ws != ws || undesc_total != L.total) {
+        std::vector<UnpackDesc> ud;
+        for (size_t i = 0; i < wk_cache.size(); ++i) {
+            const WkEntry& e = wk_cache[i];
+            if (e.transpose) continue;
+            UnpackDesc d{reinterpret_cast<const float*>(ws + L.gwk + gw_off[i]), grad[e.slot], e.N, e.Cin, e.taps, e.Kp};
+            ud.push_back(d);
+        }
+        n_unpack = (int)ud.size();
+        if (!d_undesc) TCVN_CHECK(hipMalloc(&d_undesc, ud.size() * sizeof(UnpackDesc)));
+        h_undesc.assign(reinterpret_cast<char*>(ud.data()), reinterpret_cast<char*>(ud.data()) + ud.size() * sizeof(UnpackDesc));
+        TCVN_CHECK(hipMemcpyAsync(d_undesc, h_undesc.data(), h_undesc.size(), hipMemcpyHostToDevice, st));
+        undesc_ws = ws; undesc_total = L.total;
+    }
+
+    TCVN_CHECK(hipMemsetAsync(ws + L.G[0], 0, (size_t)(L.zero_end - L.G[0]), st));
+
+    auto bwd_link = [&](const BnSlots& s, int nblk, const double* bstat, long count, float* P, float* Q, int acc, int a_slot) -> int {
+        BnBwdLinkArgs a{part, nblk, s.C, bstat, count, kEps, data[s.w], grad[s.w], grad[s.b], grad[a_slot], P, Q, acc};
+        return bn_bwd_link(a, st);
+    };
+
+    // ---- output block backward: Dropout - PReLU - BatchNorm1d - Linear ----
+    float* F = reinterpret_cast<float*>(ws + L.F);
+    float* Z = reinterpret_cast<float*>(ws + L.Z);
+    float* dF = reinterpret_cast<float*>(ws + L.dF);
+    float* dZ = reinterpret_cast<float*>(ws + L.dZ);
+    float* hs = reinterpret_cast<float*>(ws + L.head_stat);
+    {
+        RowsBnBwdArgs r{};
+        r.X = Z; r.ldx = cfg.out_dim; r.dY = d_out; r.lddy = d_out_ld; r.R = n; r.C = cfg.out_dim;
+        r.gamma = data[nl.w]; r.beta = data[nl.b]; r.slope = data[s_al]; r.save_mean = hs; r.save_rstd = hs + cfg.out_dim;
+        r.dX = dZ; r.lddx = cfg.out_dim; r.dgamma = grad[nl.w]; r.dbeta = grad[nl.b]; r.dslope = grad[s_al];
+        r.drop_p = cfg.dropout; r.seed = seed; r.stream_id = 0x4000u;
+        if ((rc = rows_bn_bwd(r, st))) return rc;
+        if ((rc = linear_bwd_dw(dZ, cfg.out_dim, F, Cf, grad[s_wl], nullptr, n, cfg.out_dim, Cf, st))) return rc;
+        if ((rc = linear_bwd_dx(dZ, cfg.out_dim, data[s_wl], dF, Cf, n, cfg.out_dim, Cf, 0, st))) return rc;
+    }
+
+    for (int bi = (int)blocks.size() - 1; bi >= 0; --bi) {
+        const BlockGeom& bg = blocks[bi];
+        const long M = (long)n * bg.H * bg.W;
+        char* D = ws + L.D[bi];
+        char* G = ws + L.G[bi];
+        float* P = reinterpret_cast<float*>(ws + L.pqD[bi]);
+        float* Q = P + bg.ld;
+        const double* bstatD = reinterpret_cast<const double*>(ws + L.bstatD[bi]);
+        const int nblkM = conv_fwd_grid((int)M);
+
+        if (!bg.has_trans) {
+            // final_norm + global average
+            HeadPoolBwdArgs a{mode, D, bg.ld, n, bg.H * bg.W, Cf, sc_of(nf), sh_of(nf), data[s_af], dF, G, bg.ld, part,
+                              head_pool_bwd_grid(n)};
+            if ((rc = head_pool_bwd(a, st))) return rc;
+            if ((rc = bwd_link(nf, a.nblk, bstatD, M, P, Q, 1, s_af))) return rc;
+        } else {
+            // transition: BN - PReLU - (pool commuted) - 1x1 conv, output = first channels of block bi+1
+            const BlockGeom& nb = blocks[bi + 1];
+            const long Mn = (long)n * nb.H * nb.W;
+            const int Nt = bg.Ctot / 2;
+            float* Pn = reinterpret_cast<float*>(ws + L.pqD[bi + 1]);
+            float* Qn = Pn + nb.ld;
+            EffSrc e{ws + L.G[bi + 1], nb.ld, ws + L.D[bi + 1], nb.ld, 0, Nt, Pn, Qn, 0.f, 0, 0};
+            const WkEntry& ef = wk_find(bg.tw, 0);
+            const WkEntry& et = wk_find(bg.tw, 1);
+            ConvWgradArgs w{};
+            w.mode = mode; w.e = e; w.dWk = gw_of(bg.tw); w.dbias = grad[bg.tb];
+            w.fa.mode = mode; w.fa.amode = A_1X1_POOL; w.fa.A = D; w.fa.lda = bg.ld; w.fa.M = (int)Mn; w.fa.N = Nt;
+            w.fa.K = bg.Ctot; w.fa.Kp = ef.Kp; w.fa.C = bg.Ctot; w.fa.H = nb.H; w.fa.W = nb.W; w.fa.Hin = bg.H; w.fa.Win = bg.W;
+            w.fa.sc = sc_of(bg.tn); w.fa.sh = sh_of(bg.tn); w.fa.sl = data[bg.ta];
+            if ((rc = conv_wgrad(w, st))) return rc;
+            ConvDgradArgs d{};
+            d.mode = mode; d.dmode = DG_1X1_POOL; d.e = e; d.M = (int)Mn; d.N = bg.Ctot; d.Kp = et.Kp;
+            d.H = nb.H; d.W = nb.W; d.Hin = bg.H; d.Win = bg.W; d.Wt = ws + L.wk + et.off;
+            d.Xin = D; d.ldxin = bg.ld; d.sc = sc_of(bg.tn); d.sh = sh_of(bg.tn); d.sl = data[bg.ta];
+            d.Gout = G; d.ldgo = bg.ld; d.accumulate = 1; d.part = part; d.nblk = conv_fwd_grid((int)Mn);
+            if ((rc = conv_dgrad(d, st))) return rc;
+            if ((rc = bwd_link(bg.tn, d.nblk, bstatD, M, P, Q, 1, bg.ta))) return rc;
+        }
+
+        for (int l = bg.L - 1; l >= 0; --l) {
+            const LayerSlots& ls = bg.layers[l];
+            char* Y = ws + L.Y[bi][l];
+            char* DU = ws + L.du;
+            float* PY = reinterpret_cast<float*>(ws + L.pqY);
+            float* QY = PY + mid;
+            const uint32_t sid = (uint32_t)(bi * 64 + l + 1);
+            // gradient of this layer's output slice D[:, cin:cin+g]
+            EffSrc e2{G, bg.ld, D, bg.ld, ls.cin, g, P + ls.cin, Q + ls.cin, cfg.dropout, seed, sid};
+            {   // conv2 (3x3) weight gradient
+                const WkEntry& ef = wk_find(ls.w2, 0);
+                ConvWgradArgs w{};
+                w.mode = mode; w.e = e2; w.dWk = gw_of(ls.w2); w.dbias = grad[ls.b2];
+                w.fa.mode = mode; w.fa.amode = A_3X3; w.fa.A = Y; w.fa.lda = mid; w.fa.M = (int)M; w.fa.N = g; w.fa.K = 9 * mid;
+                w.fa.Kp = ef.Kp; w.fa.C = mid; w.fa.H = bg.H; w.fa.W = bg.W;
+                w.fa.sc = sc_of(ls.n2); w.fa.sh = sh_of(ls.n2); w.fa.sl = data[ls.a2];
+                if ((rc = conv_wgrad(w, st))) return rc;
+            }
+            {   // conv2 data gradient -> DU (= sc2 * dU2) + norm2 partials
+                const WkEntry& et = wk_find(ls.w2, 1);
+                ConvDgradArgs d{};
+                d.mode = mode; d.dmode = DG_3X3; d.e = e2; d.M = (int)M; d.N = mid; d.Kp = et.Kp; d.H = bg.H; d.W = bg.W;
+                d.Wt = ws + L.wk + et.off; d.Xin = Y; d.ldxin = mid; d.sc = sc_of(ls.n2); d.sh = sh_of(ls.n2); d.sl = data[ls.a2];
+                d.Gout = DU; d.ldgo = mid; d.accumulate = 0; d.part = part; d.nblk = nblkM;
+                if ((rc = conv_dgrad(d, st))) return rc;
+                if ((rc = bwd_link(ls.n2, nblkM, reinterpret_cast<const double*>(ws + L.bstatY[bi][l]), M, PY, QY, 0, ls.a2))) return rc;
+            }
+            EffSrc e1{DU, mid, Y, mid, 0, mid, PY, QY, 0.f, 0, 0};
+            {   // conv1 (1x1) weight gradient
+                const WkEntry& ef = wk_find(ls.w1, 0);
+                ConvWgradArgs w{};
+                w.mode = mode; w.e = e1; w.dWk = gw_of(ls.w1); w.dbias = grad[ls.b1];
+                w.fa.mode = mode; w.fa.amode = A_1X1; w.fa.A = D; w.fa.lda = bg.ld; w.fa.M = (int)M; w.fa.N = mid; w.fa.K = ls.cin;
+                w.fa.Kp = ef.Kp; w.fa.C = ls.cin; w.fa.H = bg.H; w.fa.W = bg.W;
+                w.fa.sc = sc_of(ls.n1); w.fa.sh = sh_of(ls.n1); w.fa.sl = data[ls.a1];
+                if ((rc = conv_wgrad(w, st))) return rc;
+            }
+            {   // conv1 data gradient -> G[:, 0:cin] += sc1 * dU1, norm1 partials
+                const WkEntry& et = wk_find(ls.w1, 1);
+                ConvDgradArgs d{};
+                d.mode = mode; d.dmode = DG_1X1; d.e = e1; d.M = (int)M; d.N = ls.cin; d.Kp = et.Kp; d.H = bg.H; d.W = bg.W;
+                d.Wt = ws + L.wk + et.off; d.Xin = D; d.ldxin = bg.ld; d.sc = sc_of(ls.n1); d.sh = sh_of(ls.n1); d.sl = data[ls.a1];
+                d.Gout = G; d.ldgo = bg.ld; d.accumulate = 1; d.part = part; d.nblk = nblkM;
+                if ((rc = conv_dgrad(d, st))) return rc;
+                if ((rc = bwd_link(ls.n1, nblkM, bstatD, M, P, Q, 1, ls.a1))) return rc;
+            }
+        }
+    }
+
+    // ---- stem: AvgPool0 - PReLU0 - BN0 - conv0 ----
+    {
+        const BlockGeom& b0 = blocks[0];
+        float* P = reinterpret_cast<float*>(ws + L.pqD[0]);
+        float* Q = P + b0.ld;
+        float* P0 = reinterpret_cast<float*>(ws + L.pq0);
+        float* Q0 = P0 + cfg.init_ch;
+        const long M0 = (long)n * Hc * Wc;
+        EffSrc e{ws + L.G[0], b0.ld, ws + L.D[0], b0.ld, 0, cfg.init_ch, P, Q, 0.f, 0, 0};
+        Pool0BwdArgs a{mode, ws + L.c0, n, Hc, Wc, cfg.init_ch, sc_of(n0), sh_of(n0), data[s_a0], e, b0.H, b0.W, ws + L.du0, part,
+                       pool0_bwd_grid(n, Hc, Wc)};
+        if ((rc = pool0_bwd(a, st))) return rc;
+        if ((rc = bwd_link(n0, a.nblk, reinterpret_cast<const double*>(ws + L.bstat0), M0, P0, Q0, 0, s_a0))) return rc;
+        EffSrc e0{ws + L.du0, cfg.init_ch, ws + L.c0, cfg.init_ch, 0, cfg.init_ch, P0, Q0, 0.f, 0, 0};
+        const WkEntry& ef = wk_find(s_w0, 0);
+        ConvWgradArgs w{};
+        w.mode = mode; w.e = e0; w.dWk = gw_of(s_w0); w.dbias = grad[s_b0];
+        w.fa.mode = mode; w.fa.amode = A_STEM; w.fa.A = ws + L.img; w.fa.lda = cfg.in_ch; w.fa.M = (int)M0; w.fa.N = cfg.init_ch;
+        w.fa.K = 49 * cfg.in_ch; w.fa.Kp = ef.Kp; w.fa.C = cfg.in_ch; w.fa.H = Hc; w.fa.W = Wc; w.fa.Hin = cfg.H; w.fa.Win = cfg.W;
+        if ((rc = conv_wgrad(w, st))) return rc;
+    }
+    return unpack_wgrads(reinterpret_cast<const UnpackDesc*>(d_undesc), n_unpack, st);
+}

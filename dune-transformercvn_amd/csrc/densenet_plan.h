@@ -24,7 +24,7 @@ struct Layout {
     std::vector<long> D, bstatD;
     std::vector<std::vector<long>> Y, bstatY;
     // backward
-    long du, du0, pq0, pqY, gwk, bpart, dF, dZ;
+    long du, du0, pq0, pqY, gwk, bpart, dF, dZ, zero_end;
     std::vector<long> G, pqD;
 };
 
@@ -42,6 +42,7 @@ struct DenseNetPlan {
     char* d_desc = nullptr; size_t desc_cap = 0; std::vector<char> h_desc;
     char* desc_ws = nullptr; long desc_total = 0; int n_pack = 0, n_bneval = 0;
     uint64_t last_seed = 0; int last_n = 0;
+    char* d_undesc = nullptr; std::vector<char> h_undesc; char* undesc_ws = nullptr; long undesc_total = 0; int n_unpack = 0;
 
     explicit DenseNetPlan(const tcvn_densenet_cfg& c);
     ~DenseNetPlan();

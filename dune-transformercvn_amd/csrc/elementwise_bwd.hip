@@ -1,0 +1,177 @@
+// HBM-bound helper kernels of the DenseNet backward path.
+#include "tcvn_ops.h"
+
+namespace tcvn {
+
+namespace {
+
+// BatchNorm backward bookkeeping for one norm layer (train mode):
+//   s1 = sum dU, t2 = sum dU*x, s3 = sum dA*min(u,0)   (partials from the dgrad epilogue / pooling backward kernels)
+//   dbeta = s1 ; dgamma = sum dU*xhat = r*(t2 - mu*s1) ; dslope = s3
+//   dx = sc*dU + Px*x + Qx  with  Px = -sc*dgamma*r/M ,  Qx = -sc*s1/M + sc*dgamma*r*mu/M      (sc = gamma*r)
+__global__ __launch_bounds__(256) void k_bn_bwd_link(const BnBwdLinkArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= a.C) return;
+    double s1 = 0, t2 = 0, s3 = 0;
+    for (int b = lane; b < a.nblk; b += 64) {
+        const double* p = a.part + ((long)b * a.C + c) * 3;
+        s1 += p[0]; t2 += p[1]; s3 += p[2];
+    }
+    s1 = wave_sum(s1); t2 = wave_sum(t2); s3 = wave_sum(s3);
+    if (lane != 0) return;
+    const double mu = a.bstat[c * 2], var = a.bstat[c * 2 + 1];
+    const double r = 1.0 / sqrt(var + (double)a.eps);
+    const double dgamma = r * (t2 - mu * s1);
+    const double sc = (double)a.gamma[c] * r;
+    const double M = (double)a.count;
+    a.dgamma[c] += (float)dgamma;
+    a.dbeta[c] += (float)s1;
+    a.dslope[c] += (float)s3;
+    const float Px = (float)(-sc * dgamma * r / M);
+    const float Qx = (float)(-sc * s1 / M + sc * dgamma * r * mu / M);
+    if (a.accumulate_pq) { a.P[c] += Px; a.Q[c] += Qx; }
+    else { a.P[c] = Px; a.Q[c] = Qx; }
+}
+
+// global-average head backward: dz = dF/HW on every pixel, then PReLU+BN backward bookkeeping of final_norm
+constexpr int HP_CJ = 4;     // up to 1024 channels with 256 threads
+template <typename T>
+__global__ __launch_bounds__(256) void k_head_pool_bwd(const HeadPoolBwdArgs a) {
+    const T* X = reinterpret_cast<const T*>(a.X);
+    T* Gout = reinterpret_cast<T*>(a.Gout);
+    double s1[HP_CJ], s2[HP_CJ], s3[HP_CJ];
+#pragma unroll
+    for (int j = 0; j < HP_CJ; ++j) { s1[j] = 0; s2[j] = 0; s3[j] = 0; }
+    const float inv = 1.0f / (float)a.HW;
+    for (int img = blockIdx.x; img < a.n_img; img += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < HP_CJ; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            if (c >= a.C) continue;
+            const float sc = a.sc[c], sh = a.sh[c], sl = a.sl[c];
+            const float dz = a.dF[(long)img * a.C + c] * inv;
+            for (int p = 0; p < a.HW; ++p) {
+                const long m = (long)img * a.HW + p;
+                const float x = to_f<T>(X[m * a.ldx + c]);
+                const float u = fmaf(x, sc, sh);
+                const float du = u > 0.f ? dz : sl * dz;
+                s1[j] += du; s2[j] += (double)du * x; s3[j] += u > 0.f ? 0.f : dz * u;
+                Gout[m * a.ldgo + c] = from_f<T>(sc * du);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < HP_CJ; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < a.C) {
+            double* p = a.part + ((long)blockIdx.x * a.C + c) * 3;
+            p[0] = s1[j]; p[1] = s2[j]; p[2] = s3[j];
+        }
+    }
+}
+
+// stem tail backward: AvgPool(3, s2) -> PReLU -> BN0, over the conv0 output pixels
+constexpr int PB_CJ = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void k_pool0_bwd(const Pool0BwdArgs a) {
+    __shared__ double red[4][64 * PB_CJ][3];
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* G = reinterpret_cast<const T*>(a.e.G);
+    const T* D = reinterpret_cast<const T*>(a.e.X);
+    T* DU = reinterpret_cast<T*>(a.DU);
+    double s1[PB_CJ], s2[PB_CJ], s3[PB_CJ];
+#pragma unroll
+    for (int j = 0; j < PB_CJ; ++j) { s1[j] = 0; s2[j] = 0; s3[j] = 0; }
+    const long npix = (long)a.n_img * a.Hin * a.Win;
+    for (long p = (long)blockIdx.x * 4 + pg; p < npix; p += (long)gridDim.x * 4) {
+        const int w = (int)(p % a.Win);
+        const int h = (int)((p / a.Win) % a.Hin);
+        const long img = p / ((long)a.Win * a.Hin);
+        const int ho_lo = max(0, (h - 1) / 2), ho_hi = min(a.Ho - 1, h / 2);     // windows 2*ho <= h <= 2*ho+2
+        const int wo_lo = max(0, (w - 1) / 2), wo_hi = min(a.Wo - 1, w / 2);
+#pragma unroll
+        for (int j = 0; j < PB_CJ; ++j) {
+            const int c = cl + 64 * j;
+            if (c >= a.C) continue;
+            float dz = 0.f;
+            for (int ho = ho_lo; ho <= ho_hi; ++ho)
+                for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                    if (2 * ho > h || 2 * ho + 2 < h || 2 * wo > w || 2 * wo + 2 < w) continue;
+                    const long mo = (img * a.Ho + ho) * a.Wo + wo;
+                    dz += to_f<T>(G[mo * a.e.ldg + c]) + a.e.P[c] * to_f<T>(D[mo * a.e.ldx + c]) + a.e.Q[c];
+                }
+            dz *= (1.0f / 9.0f);
+            const float x = to_f<T>(X[p * a.C + c]);
+            const float sc = a.sc[c];
+            const float u = fmaf(x, sc, a.sh[c]);
+            const float du = u > 0.f ? dz : a.sl[c] * dz;
+            s1[j] += du; s2[j] += (double)du * x; s3[j] += u > 0.f ? 0.f : dz * u;
+            DU[p * a.C + c] = from_f<T>(sc * du);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PB_CJ; ++j) {
+        red[pg][cl + 64 * j][0] = s1[j]; red[pg][cl + 64 * j][1] = s2[j]; red[pg][cl + 64 * j][2] = s3[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        double x = 0, y = 0, z = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { x += red[q][c][0]; y += red[q][c][1]; z += red[q][c][2]; }
+        double* o = a.part + ((long)blockIdx.x * a.C + c) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+    }
+}
+
+__global__ void k_unpack(const UnpackDesc* descs) {
+    const UnpackDesc d = descs[blockIdx.y];
+    const long total = (long)d.N * d.Cin * d.taps;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % d.taps);
+        const int c = (int)((i / d.taps) % d.Cin);
+        const int n = (int)(i / ((long)d.taps * d.Cin));
+        d.dst[i] += d.src[(long)n * d.Kp + tap * d.Cin + c];
+    }
+}
+
+}  // namespace
+
+int bn_bwd_link(const BnBwdLinkArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_bwd_link, dim3(cdiv(a.C, 4)), dim3(256), 0, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int head_pool_bwd_grid(int n_img) { return n_img < 256 ? n_img : 256; }
+int head_pool_bwd(const HeadPoolBwdArgs& a, hipStream_t st) {
+    if (a.C > 256 * HP_CJ) return -2;
+    if (a.nblk != head_pool_bwd_grid(a.n_img)) return -3;
+    if (a.mode == MODE_F32) hipLaunchKernelGGL(k_head_pool_bwd<float>, dim3(a.nblk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_head_pool_bwd<bf16>, dim3(a.nblk), dim3(256), 0, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int pool0_bwd_grid(int n_img, int Hin, int Win) {
+    const long g = ((long)n_img * Hin * Win + 3) / 4;
+    return (int)(g < 2048 ? g : 2048);
+}
+int pool0_bwd(const Pool0BwdArgs& a, hipStream_t st) {
+    if (a.C > 64 * PB_CJ) return -2;
+    if (a.nblk != pool0_bwd_grid(a.n_img, a.Hin, a.Win)) return -3;
+    if (a.mode == MODE_F32) hipLaunchKernelGGL(k_pool0_bwd<float>, dim3(a.nblk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_pool0_bwd<bf16>, dim3(a.nblk), dim3(256), 0, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int unpack_wgrads(const UnpackDesc* d_descs, int n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_unpack, dim3(32, n), dim3(256), 0, st, d_descs);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace tcvn

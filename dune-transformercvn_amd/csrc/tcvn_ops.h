@@ -76,4 +76,74 @@ int head_pool_fwd(const HeadPoolArgs& a, hipStream_t st);
 struct PackDesc { const float* src; void* dst; int N, Cin, taps, Kp; int transpose; };
 int pack_weights(const PackDesc* d_descs, int n, int mode, hipStream_t st);
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward convolutions
+// ---------------------------------------------------------------------------------------------------------
+// Effective output gradient of a produced tensor X (one dense-layer output slice, a bottleneck output, a transition
+// output or conv0's output):   eff(m, n) = drop(m, n) * ( G[m][c_off+n] + P[n] * X[m][c_off+n] + Q[n] )
+// G holds the sum over consumers of (gamma*rstd) * dU; P/Q carry the batch-mean terms of every consumer BatchNorm's
+// backward (they are affine in X, so they are accumulated per channel instead of per element).
+struct EffSrc {
+    const void* G; long ldg;
+    const void* X; long ldx;
+    int c_off, N;
+    const float *P, *Q;
+    float drop_p; uint64_t seed; uint32_t stream_id;
+};
+
+enum DMode { DG_1X1 = 0, DG_1X1_POOL = 1, DG_3X3 = 2 };
+// dA[m][c] = sum_k eff(...) * Wt[c][k], followed by the PReLU + BatchNorm backward of the consumer norm:
+//   u = sc*x + sh ; dU = dA * prelu'(u) ; Gout[m][c] (+)= sc * dU ; partial sums (sum dU, sum dU*x, sum dA*min(u,0))
+struct ConvDgradArgs {
+    int mode, dmode;
+    EffSrc e;
+    int M, N, Kp;
+    int H, W, Hin, Win;
+    const void* Wt;
+    const void* Xin; long ldxin;
+    const float *sc, *sh, *sl;
+    void* Gout; long ldgo; int accumulate;
+    double* part; int nblk;        // [nblk][N][3]
+};
+int conv_dgrad(const ConvDgradArgs& a, hipStream_t st);
+
+// dWk[n][k] += sum_m eff(m, n) * a(m, k)   (a = the forward A operand, regenerated), dbias[n] += sum_m eff(m, n)
+struct ConvWgradArgs {
+    int mode;
+    ConvFwdArgs fa;
+    EffSrc e;
+    float* dWk; float* dbias;
+};
+int conv_wgrad(const ConvWgradArgs& a, hipStream_t st);
+
+// Reduce the backward partials of one BatchNorm, emit parameter gradients and the (P, Q) coefficients of its input.
+struct BnBwdLinkArgs {
+    const double* part; int nblk; int C;
+    const double* bstat;                 // (mean, biased var) of the BN input channels
+    long count; float eps;
+    const float* gamma;
+    float *dgamma, *dbeta, *dslope;      // accumulated
+    float *P, *Q; int accumulate_pq;
+};
+int bn_bwd_link(const BnBwdLinkArgs& a, hipStream_t st);
+
+// head: dF[img][c] -> G of the last block (+ partials);  stem tail: eff of block-1's first channels -> DU0 (+ partials)
+struct HeadPoolBwdArgs {
+    int mode; const void* X; long ldx; int n_img, HW, C; const float *sc, *sh, *sl; const float* dF;
+    void* Gout; long ldgo; double* part; int nblk;
+};
+int head_pool_bwd(const HeadPoolBwdArgs& a, hipStream_t st);
+int head_pool_bwd_grid(int n_img);
+struct Pool0BwdArgs {
+    int mode; const void* X; int n_img, Hin, Win, C; const float *sc, *sh, *sl;   // X = conv0 output
+    EffSrc e; int Ho, Wo;                                                          // gradient of the pooled map
+    void* DU; double* part; int nblk;
+};
+int pool0_bwd(const Pool0BwdArgs& a, hipStream_t st);
+int pool0_bwd_grid(int n_img, int Hin, int Win);
+
+// kernel-layout fp32 weight gradients -> reference OIHW gradients (accumulate)
+struct UnpackDesc { const float* src; float* dst; int N, Cin, taps, Kp; };
+int unpack_wgrads(const UnpackDesc* d_descs, int n, hipStream_t st);
+
 }  // namespace tcvn

@@ -62,3 +62,72 @@ def test_densenet_forward_fp32(name, training):
         for k in ("features.norm0.running_mean", "features.norm0.running_var", "output_block.norm.running_var",
                   "features.final_norm.running_mean"):
             assert rel_err(data[k].cpu(), ctx.new_running[PFX + "." + k]) < 1e-4, k
+
+
+def _oracle_grads(cfg, sd, batch, d_out, dtype=torch.float64):
+    """fp64 autograd of the oracle DenseNet in train mode (dropout 0): gradients of sum(out * d_out)."""
+    sub = {}
+    leaves = {}
+    for k, v in sd.items():
+        if not k.startswith(PFX + "."):
+            continue
+        if v.is_floating_point():
+            t = v.to(dtype)
+            if not k.endswith(("running_mean", "running_var")):
+                t = t.clone().requires_grad_(True)
+                leaves[k] = t
+            sub[k] = t
+        else:
+            sub[k] = v
+    ctx = O._Ctx(True, 0.0)
+    px = O.preprocess_pixels(cfg, batch[5], batch[6].to(dtype), False)
+    out = O.densenet_forward(sub, PFX, cfg, px, ctx)
+    (out * d_out.to(dtype)).sum().backward()
+    return {k[len(PFX) + 1:]: t.grad for k, t in leaves.items()}, out.detach()
+
+
+def _mid_case():
+    """Shallow network with the tutorial's channel widths: exercises the 64/128-wide wgrad tiles and >128-channel
+    dgrad column tiles while keeping fp32 rounding noise low enough for a tight comparison."""
+    over = dict(densenet_structure=[3, 2], num_encoder_layers=2)
+    cfg = O.tutorial_config(**over)
+    batch = O.synthetic_batch([2, 1], 21, cfg)
+    return cfg, over, batch, {"weight_seed": 7}
+
+
+# fp32 noise floor, measured on the oracle itself (fp32 vs fp64 autograd of the same graph): <= 1e-4 for the shallow
+# nets, up to 1.3e-2 (max-norm) for the 30-layer tutorial net on 8 images -- PReLU kinks make the deep net's gradients
+# sensitive to 1e-7 perturbations.  The deep case therefore gets a loose max-norm band plus an L2 bound.
+@pytest.mark.parametrize("name,tol_max,tol_l2", [("small_b3", 2e-3, 1e-3), ("mid", 2e-3, 1e-3), ("tutorial_b2p4", 6e-2, 1e-2)])
+def test_densenet_backward_fp32(name, tol_max, tol_l2):
+    cfg, over, batch, g = _mid_case() if name == "mid" else load_case(name)
+    cfg = train_cfg(over)
+    sd = O.fill_state(cfg, int(g["weight_seed"]))
+    n_img = int(batch[7].sum())
+    gen = torch.Generator().manual_seed(5)
+    d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=gen)
+    ref, ref_out = _oracle_grads(cfg, sd, batch, d_out)
+    eng, data, grads = _engine(cfg, sd, with_grad=True)
+    out = torch.empty(n_img, eng.out_dim, device="cuda")
+    eng.forward(batch[5].cuda(), batch[6].cuda(), n_img, out, train=True, seed=1)
+    eng.backward(d_out.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref_out) < 1e-4
+    bad = []
+    worst = worst_l2 = 0.0
+    for k, r in ref.items():
+        mine = grads[k].cpu().double().reshape(r.shape)
+        scale = r.abs().max().item()
+        err = (mine - r).abs().max().item()
+        is_bias = k.endswith(("conv0.bias", "conv1.bias", "conv2.bias", "conv.bias"))
+        if is_bias:                       # exact gradient is 0 (a train-mode BatchNorm follows): rounding noise only
+            ok = mine.abs().max().item() < 5e-3
+        else:
+            l2 = ((mine - r).norm() / r.norm().clamp_min(1e-30)).item()
+            ok = err <= tol_max * scale + 1e-7 and l2 <= tol_l2
+            worst = max(worst, err / max(scale, 1e-30))
+            worst_l2 = max(worst_l2, l2)
+        if not ok:
+            bad.append((k, err, scale))
+    print(name, "worst relative grad error: max-norm", worst, "l2", worst_l2, "bad", bad[:8])
+    assert not bad, bad[:8]
