@@ -67,7 +67,7 @@ __global__ void k_scatter(const ScatterArgs a) {
     T* o = reinterpret_cast<T*>(a.img) + (((long)img * a.H + y) * a.W + x) * a.Cpix;
     for (int c = 0; c < a.Cpix; ++c) {
         float v = a.values[i * a.Cpix + c];
-        v = a.log_pixels ? logf(v + 1.f) : v / 255.0f;
+        v = a.log_pixels == 1 ? logf(v + 1.f) : a.log_pixels == 0 ? v / 255.0f : v;   // 2: already preprocessed
         if (a.noise_std != 0.f) {             // v * (1 + N(0,1) * std): Box-Muller on two counter-based uniforms
             const float u1 = fmaxf(rng_uniform(a.seed, 0x6e6f6973u, (uint64_t)(i * a.Cpix + c) * 2), 1e-7f);
             const float u2 = rng_uniform(a.seed, 0x6e6f6973u, (uint64_t)(i * a.Cpix + c) * 2 + 1);

@@ -1,20 +1,335 @@
-// Token path engine (combined embedding, encoder, decoders, focal loss) -- C ABI entry points.
+// Token path engine: combined embedding (LinearBlock), transformer encoder, event / prong decoders and the softmax
+// focal loss; forward, loss and backward on one stream.  Reference call chain:
+//   networks/neutrino_full_base_network.py:113-125 (combined embedding, pad), :184-188 (encoder, decoders)
+//   layers/prong_custom_bert_encoder.py:57-75, layers/prong_decoder.py:15-16, layers/prong_target_decoder.py:34-41
+//   trainers/neutrino_full_base_trainer.py:148-177 (loss)
+// All arithmetic fp32 (this path is < 0.03 % of the FLOPs).
+#include <string>
+#include <vector>
+#include <cstring>
+
 #include "../../include/tcvn_hip.h"
 #include "head_plan.h"
+#include "tcvn_rows.h"
+#include "tcvn_encoder.h"
+
+using namespace tcvn;
+
+namespace {
+constexpr float kEps = 1e-5f, kMom = 0.1f;
+
+__global__ void k_combine_loss(const float* oe, const float* op, float ew, float* losses, float* accs) {
+    losses[0] = ew * oe[0] + (1.f - ew) * op[0];
+    losses[1] = oe[0]; losses[2] = op[0];
+    accs[0] = oe[1]; accs[1] = op[1];
+}
+__global__ void k_scale(float* x, long n, float s) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= s;
+}
+struct Bump {
+    long off = 0;
+    long take(long bytes) { long o = off; off += round_up(bytes, 256); return o; }
+};
+}  // namespace
+
+int HeadPlan::add_slot(const std::string& name, long numel, int kind) {
+    slots.push_back({name, numel, kind});
+    return (int)slots.size() - 1;
+}
+HBn HeadPlan::add_bn(const std::string& p, int c) {
+    HBn s;
+    s.w = add_slot(p + ".weight", c, TCVN_SLOT_PARAM);
+    s.b = add_slot(p + ".bias", c, TCVN_SLOT_PARAM);
+    s.rm = add_slot(p + ".running_mean", c, TCVN_SLOT_BUFFER);
+    s.rv = add_slot(p + ".running_var", c, TCVN_SLOT_BUFFER);
+    add_slot(p + ".num_batches_tracked", 1, TCVN_SLOT_COUNTER);
+    return s;
+}
+
+HeadPlan::HeadPlan(const tcvn_head_cfg& c) : cfg(c) {
+    const int D = cfg.hidden_dim;
+    const std::string ce = "prong_embedding.combined_embedding";
+    cw = add_slot(ce + ".linear.weight", (long)D * cfg.in_dim, TCVN_SLOT_PARAM);
+    cn = add_bn(ce + ".norm", D);
+    ca = add_slot(ce + ".activation.weight", D, TCVN_SLOT_PARAM);
+    for (int l = 0; l < cfg.n_layers; ++l) {
+        const std::string p = "encoder.encoder.layers." + std::to_string(l);
+        HLayer L;
+        L.win = add_slot(p + ".self_attn.in_proj_weight", 3L * D * D, TCVN_SLOT_PARAM);
+        L.bin = add_slot(p + ".self_attn.in_proj_bias", 3 * D, TCVN_SLOT_PARAM);
+        L.wo = add_slot(p + ".self_attn.out_proj.weight", (long)D * D, TCVN_SLOT_PARAM);
+        L.bo = add_slot(p + ".self_attn.out_proj.bias", D, TCVN_SLOT_PARAM);
+        L.w1 = add_slot(p + ".linear1.weight", (long)D * D, TCVN_SLOT_PARAM);
+        L.b1 = add_slot(p + ".linear1.bias", D, TCVN_SLOT_PARAM);
+        L.w2 = add_slot(p + ".linear2.weight", (long)D * D, TCVN_SLOT_PARAM);
+        L.b2 = add_slot(p + ".linear2.bias", D, TCVN_SLOT_PARAM);
+        L.g1 = add_slot(p + ".norm1.weight", D, TCVN_SLOT_PARAM);
+        L.be1 = add_slot(p + ".norm1.bias", D, TCVN_SLOT_PARAM);
+        L.g2 = add_slot(p + ".norm2.weight", D, TCVN_SLOT_PARAM);
+        L.be2 = add_slot(p + ".norm2.bias", D, TCVN_SLOT_PARAM);
+        layers.push_back(L);
+    }
+    ew = add_slot("event_decoder.hidden_layer.weight", (long)cfg.event_classes * D, TCVN_SLOT_PARAM);
+    eb = add_slot("event_decoder.hidden_layer.bias", cfg.event_classes, TCVN_SLOT_PARAM);
+    int idx = 0, in = D;
+    for (int i = 0; i < cfg.n_dec; ++i) {
+        const std::string p = "prong_decoder.hidden_layers.";
+        HDec d;
+        d.in = in; d.out = cfg.dec_dims[i];
+        d.w = add_slot(p + std::to_string(idx) + ".weight", (long)d.out * d.in, TCVN_SLOT_PARAM);
+        d.b = add_slot(p + std::to_string(idx) + ".bias", d.out, TCVN_SLOT_PARAM);
+        d.n = add_bn(p + std::to_string(idx + 1), d.out);
+        d.a = add_slot(p + std::to_string(idx + 2) + ".weight", d.out, TCVN_SLOT_PARAM);
+        idx += 3 + (cfg.dropout_modules ? 1 : 0);
+        in = d.out;
+        dec.push_back(d);
+    }
+    dec_width = in;
+    ow = add_slot("prong_decoder.output_layer.weight", (long)cfg.prong_classes * cfg.dec_out_in, TCVN_SLOT_PARAM);
+    ob = add_slot("prong_decoder.output_layer.bias", cfg.prong_classes, TCVN_SLOT_PARAM);
+    data.assign(slots.size(), nullptr);
+    grad.assign(slots.size(), nullptr);
+}
+
+int HeadPlan::bind(void* const* d, void* const* g) {
+    for (size_t i = 0; i < slots.size(); ++i) {
+        data[i] = reinterpret_cast<float*>(d[i]);
+        grad[i] = g ? reinterpret_cast<float*>(g[i]) : nullptr;
+        if (slots[i].kind != TCVN_SLOT_COUNTER && data[i] == nullptr) return -10;
+    }
+    bound = true;
+    return 0;
+}
+
+void HeadPlan::layout(int B, int P, int nP, HLayout& L) const {
+    Bump b;
+    const int D = cfg.hidden_dim, S = 1 + P, T = S * B, R = B + nP, TP = P * B, H = cfg.heads;
+    const long td = (long)T * D * 4;
+    L.Zc = b.take((long)R * D * 4); L.C = b.take((long)R * D * 4); L.cstat = b.take(2L * D * 4);
+    L.X.clear(); L.lay.clear();
+    for (int l = 0; l <= cfg.n_layers; ++l) L.X.push_back(b.take(td));
+    for (int l = 0; l < cfg.n_layers; ++l) {
+        HLayBuf q;
+        q.qkv = b.take(3 * td); q.probs = b.take((long)B * H * S * S * 4); q.ctx = b.take(td); q.ao = b.take(td);
+        q.xh1 = b.take(td); q.rstd1 = b.take((long)T * 4); q.x1 = b.take(td); q.hpre = b.take(td); q.hact = b.take(td);
+        q.f = b.take(td); q.xh2 = b.take(td); q.rstd2 = b.take((long)T * 4);
+        L.lay.push_back(q);
+    }
+    L.HID = b.take(td);
+    L.Zd.clear(); L.Ad.clear(); L.dstat.clear();
+    for (const auto& d : dec) {
+        L.Zd.push_back(b.take((long)TP * d.out * 4)); L.Ad.push_back(b.take((long)TP * d.out * 4));
+        L.dstat.push_back(b.take(2L * d.out * 4));
+    }
+    L.LG = b.take((long)TP * cfg.prong_classes * 4);
+    L.dEv = b.take((long)B * cfg.event_classes * 4); L.dPr = b.take((long)B * P * cfg.prong_classes * 4);
+    L.lossbuf = b.take(64);
+    // backward scratch
+    L.dLG = b.take((long)TP * cfg.prong_classes * 4);
+    L.t0 = b.take(3 * td); L.t1 = b.take(3 * td); L.t2 = b.take(td); L.t3 = b.take(td); L.dHID = b.take(td);
+    L.dC = b.take((long)R * D * 4); L.dZc = b.take((long)R * D * 4);
+    L.total = b.off;
+}
+
+int HeadPlan::forward(int B, int P, int nP, const float* rows, const int32_t* tok_row, float* ev_logits, float* pr_logits,
+                      char* ws, long ws_bytes, int train, uint64_t seed, hipStream_t st) {
+    if (!bound) return -11;
+    if (cfg.norm_first) { fprintf(stderr, "tcvn: transformer_norm_first is not implemented\n"); return -20; }
+    if (cfg.dec_out_in != dec_width) { fprintf(stderr, "tcvn: prong decoder width mismatch (reference would fail too)\n"); return -21; }
+    HLayout L;
+    layout(B, P, nP, L);
+    if (ws_bytes < L.total) return -12;
+    const int D = cfg.hidden_dim, S = 1 + P, T = S * B, R = B + nP, TP = P * B, H = cfg.heads, hd = D / H;
+    const float dp = train ? cfg.dropout : 0.f;
+    auto F = [&](long off) { return reinterpret_cast<float*>(ws + off); };
+    int rc;
+    if ((rc = linear_fwd(rows, cfg.in_dim, data[cw], nullptr, F(L.Zc), D, R, D, cfg.in_dim, st))) return rc;
+    {
+        RowsBnArgs r{};
+        r.X = F(L.Zc); r.ldx = D; r.R = R; r.C = D; r.gamma = data[cn.w]; r.beta = data[cn.b]; r.slope = data[ca];
+        r.running_mean = data[cn.rm]; r.running_var = data[cn.rv]; r.Y = F(L.C); r.ldy = D;
+        r.save_mean = F(L.cstat); r.save_rstd = F(L.cstat) + D; r.train = train; r.eps = kEps; r.momentum = kMom;
+        r.drop_p = dp; r.seed = seed; r.stream_id = 0x5000u;
+        if ((rc = rows_bn_fwd(r, st))) return rc;
+    }
+    if ((rc = gather_tokens(F(L.C), tok_row, F(L.X[0]), B, S, D, st))) return rc;
+    for (int l = 0; l < cfg.n_layers; ++l) {
+        const HLayer& W = layers[l];
+        const HLayBuf& q = L.lay[l];
+        const uint32_t sid = 0x6000u + l * 8;
+        if ((rc = linear_fwd(F(L.X[l]), D, data[W.win], data[W.bin], F(q.qkv), 3 * D, T, 3 * D, D, st))) return rc;
+        AttnArgs a{F(q.qkv), tok_row, F(q.probs), F(q.ctx), B, S, H, hd, dp, seed, sid};
+        if ((rc = attn_fwd(a, st))) return rc;
+        if ((rc = linear_fwd(F(q.ctx), D, data[W.wo], data[W.bo], F(q.ao), D, T, D, D, st))) return rc;
+        AddLnArgs n1{F(L.X[l]), F(q.ao), data[W.g1], data[W.be1], F(q.x1), F(q.xh1), F(q.rstd1), T, D, kEps, dp, seed, sid + 1};
+        if ((rc = add_ln_fwd(n1, st))) return rc;
+        if ((rc = linear_fwd(F(q.x1), D, data[W.w1], data[W.b1], F(q.hpre), D, T, D, D, st))) return rc;
+        if ((rc = act_fwd(F(q.hpre), F(q.hact), (long)T * D, cfg.gelu, dp, seed, sid + 2, st))) return rc;
+        if ((rc = linear_fwd(F(q.hact), D, data[W.w2], data[W.b2], F(q.f), D, T, D, D, st))) return rc;
+        AddLnArgs n2{F(q.x1), F(q.f), data[W.g2], data[W.be2], F(L.X[l + 1]), F(q.xh2), F(q.rstd2), T, D, kEps, dp, seed, sid + 3};
+        if ((rc = add_ln_fwd(n2, st))) return rc;
+    }
+    if ((rc = mask_rows(F(L.X[cfg.n_layers]), tok_row, F(L.HID), B, S, D, st))) return rc;
+    if ((rc = linear_fwd(F(L.HID), D, data[ew], data[eb], ev_logits, cfg.event_classes, B, cfg.event_classes, D, st))) return rc;
+    const float* in = F(L.HID) + (long)B * D;
+    int inw = D;
+    for (size_t i = 0; i < dec.size(); ++i) {
+        const HDec& d = dec[i];
+        if ((rc = linear_fwd(in, inw, data[d.w], data[d.b], F(L.Zd[i]), d.out, TP, d.out, d.in, st))) return rc;
+        RowsBnArgs r{};
+        r.X = F(L.Zd[i]); r.ldx = d.out; r.R = TP; r.C = d.out; r.gamma = data[d.n.w]; r.beta = data[d.n.b]; r.slope = data[d.a];
+        r.running_mean = data[d.n.rm]; r.running_var = data[d.n.rv]; r.Y = F(L.Ad[i]); r.ldy = d.out;
+        r.save_mean = F(L.dstat[i]); r.save_rstd = F(L.dstat[i]) + d.out; r.train = train; r.eps = kEps; r.momentum = kMom;
+        r.drop_p = cfg.dropout_modules ? dp : 0.f; r.seed = seed; r.stream_id = 0x7000u + (uint32_t)i;
+        if ((rc = rows_bn_fwd(r, st))) return rc;
+        in = F(L.Ad[i]); inw = d.out;
+    }
+    if ((rc = linear_fwd(in, inw, data[ow], data[ob], F(L.LG), cfg.prong_classes, TP, cfg.prong_classes, cfg.dec_out_in, st))) return rc;
+    if ((rc = permute_rows(F(L.LG), pr_logits, B, P, cfg.prong_classes, 1, st))) return rc;
+    last_seed = seed; last_train = train;
+    return 0;
+}
+
+int HeadPlan::loss(int B, int P, const float* ev_logits, const float* pr_logits, const int64_t* et, const int8_t* pt, float* losses,
+                   float* accs, float* dEv, float* dPr, hipStream_t st) {
+    int rc;
+    float* lb = accs + 2;                       // accs has room for 2 + 4 floats (scratch behind the two accuracies)
+    if ((rc = focal_i64(ev_logits, et, B, cfg.event_classes, cfg.gamma, cfg.event_weight, dEv, lb, st))) return rc;
+    if ((rc = focal_i8(pr_logits, pt, B * P, cfg.prong_classes, cfg.gamma, 1.f - cfg.event_weight, dPr, lb + 2, st))) return rc;
+    hipLaunchKernelGGL(k_combine_loss, dim3(1), dim3(1), 0, st, lb, lb + 2, cfg.event_weight, losses, accs);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int HeadPlan::backward(int B, int P, int nP, const float* rows, const int32_t* tok_row, const float* dEv, const float* dPr,
+                       float* d_rows, char* ws, long ws_bytes, hipStream_t st) {
+    if (!bound) return -11;
+    for (size_t i = 0; i < slots.size(); ++i)
+        if (slots[i].kind == TCVN_SLOT_PARAM && grad[i] == nullptr) return -14;
+    HLayout L;
+    layout(B, P, nP, L);
+    if (ws_bytes < L.total) return -12;
+    const int D = cfg.hidden_dim, S = 1 + P, T = S * B, R = B + nP, TP = P * B, H = cfg.heads, hd = D / H;
+    const int Ce = cfg.event_classes, Cp = cfg.prong_classes;
+    const float dp = cfg.dropout;
+    const uint64_t seed = last_seed;
+    auto F = [&](long off) { return reinterpret_cast<float*>(ws + off); };
+    int rc;
+    // ---- prong decoder ----
+    if ((rc = permute_rows(dPr, F(L.dLG), B, P, Cp, 0, st))) return rc;
+    float* dHID = F(L.dHID);
+    const float* last_in = dec.empty() ? F(L.HID) + (long)B * D : F(L.Ad[dec.size() - 1]);
+    const int last_w = dec.empty() ? D : dec.back().out;
+    if ((rc = linear_bwd_dw(F(L.dLG), Cp, last_in, last_w, grad[ow], grad[ob], TP, Cp, last_w, st))) return rc;
+    float* dA = F(L.t0);
+    float* dZ = F(L.t1);
+    float* dst0 = dec.empty() ? dHID + (long)B * D : dA;
+    if ((rc = linear_bwd_dx(F(L.dLG), Cp, data[ow], dst0, dec.empty() ? D : last_w, TP, Cp, last_w, 0, st))) return rc;
+    for (int i = (int)dec.size() - 1; i >= 0; --i) {
+        const HDec& d = dec[i];
+        RowsBnBwdArgs r{};
+        r.X = F(L.Zd[i]); r.ldx = d.out; r.dY = dA; r.lddy = d.out; r.R = TP; r.C = d.out;
+        r.gamma = data[d.n.w]; r.beta = data[d.n.b]; r.slope = data[d.a]; r.save_mean = F(L.dstat[i]); r.save_rstd = F(L.dstat[i]) + d.out;
+        r.dX = dZ; r.lddx = d.out; r.dgamma = grad[d.n.w]; r.dbeta = grad[d.n.b]; r.dslope = grad[d.a];
+        r.drop_p = cfg.dropout_modules ? dp : 0.f; r.seed = seed; r.stream_id = 0x7000u + (uint32_t)i;
+        if ((rc = rows_bn_bwd(r, st))) return rc;
+        const float* in = i == 0 ? F(L.HID) + (long)B * D : F(L.Ad[i - 1]);
+        const int inw = i == 0 ? D : dec[i - 1].out;
+        if ((rc = linear_bwd_dw(dZ, d.out, in, inw, grad[d.w], grad[d.b], TP, d.out, d.in, st))) return rc;
+        float* dIn = i == 0 ? dHID + (long)B * D : dA;
+        if ((rc = linear_bwd_dx(dZ, d.out, data[d.w], dIn, inw, TP, d.out, d.in, 0, st))) return rc;
+    }
+    // ---- event decoder ----
+    if ((rc = linear_bwd_dw(dEv, Ce, F(L.HID), D, grad[ew], grad[eb], B, Ce, D, st))) return rc;
+    if ((rc = linear_bwd_dx(dEv, Ce, data[ew], dHID, D, B, Ce, D, 0, st))) return rc;
+    // ---- encoder ----
+    float* dX = F(L.t2);
+    if ((rc = mask_rows(dHID, tok_row, dX, B, S, D, st))) return rc;
+    float* d1 = F(L.t3);
+    float* dR = F(L.t0);
+    float* dT = F(L.t1);
+    for (int l = cfg.n_layers - 1; l >= 0; --l) {
+        const HLayer& W = layers[l];
+        const HLayBuf& q = L.lay[l];
+        const uint32_t sid = 0x6000u + l * 8;
+        AddLnBwdArgs n2{dX, F(q.xh2), F(q.rstd2), data[W.g2], d1, dR, grad[W.g2], grad[W.be2], T, D, dp, seed, sid + 3};
+        if ((rc = add_ln_bwd(n2, st))) return rc;                                   // d1 = d(x1) residual, dR = d(f)
+        if ((rc = linear_bwd_dw(dR, D, F(q.hact), D, grad[W.w2], grad[W.b2], T, D, D, st))) return rc;
+        if ((rc = linear_bwd_dx(dR, D, data[W.w2], dT, D, T, D, D, 0, st))) return rc;      // dT = d(hact)
+        if ((rc = act_bwd(F(q.hpre), dT, dR, (long)T * D, cfg.gelu, dp, seed, sid + 2, st))) return rc;   // dR = d(hpre)
+        if ((rc = linear_bwd_dw(dR, D, F(q.x1), D, grad[W.w1], grad[W.b1], T, D, D, st))) return rc;
+        if ((rc = linear_bwd_dx(dR, D, data[W.w1], d1, D, T, D, D, 1, st))) return rc;      // d1 += through FFN
+        AddLnBwdArgs n1{d1, F(q.xh1), F(q.rstd1), data[W.g1], dX, dR, grad[W.g1], grad[W.be1], T, D, dp, seed, sid + 1};
+        if ((rc = add_ln_bwd(n1, st))) return rc;                                   // dX = d(x_l) residual, dR = d(ao)
+        if ((rc = linear_bwd_dw(dR, D, F(q.ctx), D, grad[W.wo], grad[W.bo], T, D, D, st))) return rc;
+        if ((rc = linear_bwd_dx(dR, D, data[W.wo], dT, D, T, D, D, 0, st))) return rc;      // dT = d(ctx)
+        AttnBwdArgs ab{F(q.qkv), F(q.probs), dT, dR, B, S, H, hd, dp, seed, sid};       // dR = d(qkv) [T, 3D]
+        if ((rc = attn_bwd(ab, st))) return rc;
+        if ((rc = linear_bwd_dw(dR, 3 * D, F(L.X[l]), D, grad[W.win], grad[W.bin], T, 3 * D, D, st))) return rc;
+        if ((rc = linear_bwd_dx(dR, 3 * D, data[W.win], dX, D, T, 3 * D, D, 1, st))) return rc;
+    }
+    // ---- combined embedding ----
+    if ((rc = scatter_tokens_bwd(dX, tok_row, F(L.dC), B, S, D, st))) return rc;
+    {
+        RowsBnBwdArgs r{};
+        r.X = F(L.Zc); r.ldx = D; r.dY = F(L.dC); r.lddy = D; r.R = R; r.C = D;
+        r.gamma = data[cn.w]; r.beta = data[cn.b]; r.slope = data[ca]; r.save_mean = F(L.cstat); r.save_rstd = F(L.cstat) + D;
+        r.dX = F(L.dZc); r.lddx = D; r.dgamma = grad[cn.w]; r.dbeta = grad[cn.b]; r.dslope = grad[ca];
+        r.drop_p = dp; r.seed = seed; r.stream_id = 0x5000u;
+        if ((rc = rows_bn_bwd(r, st))) return rc;
+    }
+    if ((rc = linear_bwd_dw(F(L.dZc), D, rows, cfg.in_dim, grad[cw], nullptr, R, D, cfg.in_dim, st))) return rc;
+    return linear_bwd_dx(F(L.dZc), D, data[cw], d_rows, cfg.in_dim, R, D, cfg.in_dim, 0, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct tcvn_head { HeadPlan plan; int last_np = 0; explicit tcvn_head(const tcvn_head_cfg& c) : plan(c) {} };
 
 extern "C" {
-int tcvn_head_create(const tcvn_head_cfg* cfg, tcvn_head** out) { (void)cfg; (void)out; return -100; }
-void tcvn_head_destroy(tcvn_head* p) { (void)p; }
-int tcvn_head_num_slots(const tcvn_head* p) { (void)p; return 0; }
-int tcvn_head_slot(const tcvn_head* p, int i, char* name, int cap, int64_t* numel, int* kind) { return -100; }
-int tcvn_head_bind(tcvn_head* p, void* const* data, void* const* grad) { return -100; }
-int64_t tcvn_head_workspace_bytes(const tcvn_head* p, int batch, int max_prongs, int n_prongs) { return 0; }
+int tcvn_head_create(const tcvn_head_cfg* cfg, tcvn_head** out) {
+    if (!cfg || !out || cfg->n_dec < 0 || cfg->n_dec > 8 || cfg->hidden_dim % cfg->heads != 0) return -1;
+    *out = new tcvn_head(*cfg);
+    return 0;
+}
+void tcvn_head_destroy(tcvn_head* p) { delete p; }
+int tcvn_head_num_slots(const tcvn_head* p) { return (int)p->plan.slots.size(); }
+int tcvn_head_slot(const tcvn_head* p, int i, char* name, int cap, int64_t* numel, int* kind) {
+    if (i < 0 || i >= (int)p->plan.slots.size()) return -1;
+    const auto& s = p->plan.slots[i];
+    if (name && cap > 0) { strncpy(name, s.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (numel) *numel = s.numel;
+    if (kind) *kind = s.kind;
+    return 0;
+}
+int tcvn_head_bind(tcvn_head* p, void* const* data, void* const* grad) { return p->plan.bind(data, grad); }
+int64_t tcvn_head_workspace_bytes(const tcvn_head* p, int batch, int max_prongs, int n_prongs) {
+    HLayout L;
+    p->plan.layout(batch, max_prongs, n_prongs, L);
+    return L.total;
+}
 int tcvn_head_forward(tcvn_head* p, int batch, int max_prongs, int n_prongs, const float* rows, const int32_t* tok_row,
-                      float* event_logits, float* prong_logits, void* workspace, int64_t workspace_bytes, int train,
-                      uint64_t seed, void* stream) { return -100; }
+                      float* event_logits, float* prong_logits, void* ws, int64_t ws_bytes, int train, uint64_t seed, void* stream) {
+    p->last_np = n_prongs;
+    return p->plan.forward(batch, max_prongs, n_prongs, rows, tok_row, event_logits, prong_logits, reinterpret_cast<char*>(ws),
+                           ws_bytes, train, seed, reinterpret_cast<hipStream_t>(stream));
+}
 int tcvn_head_loss(tcvn_head* p, int batch, int max_prongs, const float* event_logits, const float* prong_logits,
-                   const int64_t* event_targets, const int8_t* prong_targets, float* losses, float* accs, void* workspace,
-                   int64_t workspace_bytes, void* stream) { return -100; }
+                   const int64_t* event_targets, const int8_t* prong_targets, float* losses, float* accs, float* d_event_logits,
+                   float* d_prong_logits, void* stream) {
+    return p->plan.loss(batch, max_prongs, event_logits, prong_logits, event_targets, prong_targets, losses, accs, d_event_logits,
+                        d_prong_logits, reinterpret_cast<hipStream_t>(stream));
+}
 int tcvn_head_backward(tcvn_head* p, int batch, int max_prongs, int n_prongs, const float* rows, const int32_t* tok_row,
-                       float loss_scale, float* d_rows, void* workspace, int64_t workspace_bytes, void* stream) { return -100; }
+                       const float* d_event_logits, const float* d_prong_logits, float* d_rows, void* ws, int64_t ws_bytes,
+                       void* stream) {
+    return p->plan.backward(batch, max_prongs, n_prongs, rows, tok_row, d_event_logits, d_prong_logits, d_rows,
+                            reinterpret_cast<char*>(ws), ws_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+}
+
+// Stand-alone softmax focal loss of one logit matrix (reference: NeutrinoFullBaseTrainer.loss, :148-160)
+extern "C" int tcvn_focal_loss(const float* logits, const int64_t* targets, int rows, int classes, float gamma, float weight,
+                               float* d_logits, float* out2, void* stream) {
+    return focal_i64(logits, targets, rows, classes, gamma, weight, d_logits, out2, reinterpret_cast<hipStream_t>(stream));
 }

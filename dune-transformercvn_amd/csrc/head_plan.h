@@ -1,1 +1,46 @@
+// Token-path plan: slot table, workspace layout, forward / loss / backward drivers.
 #pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/tcvn_hip.h"
+#include "tcvn_common.h"
+#include "densenet_plan.h"   // Slot
+
+namespace tcvn {
+
+struct HBn { int w, b, rm, rv; };
+struct HLayer { int win, bin, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2; };
+struct HDec { int w, b, a, in, out; HBn n; };
+struct HLayBuf { long qkv, probs, ctx, ao, xh1, rstd1, x1, hpre, hact, f, xh2, rstd2; };
+struct HLayout {
+    long Zc, C, cstat, HID, LG, dEv, dPr, lossbuf, dLG, t0, t1, t2, t3, dHID, dC, dZc, total;
+    std::vector<long> X, Zd, Ad, dstat;
+    std::vector<HLayBuf> lay;
+};
+
+struct HeadPlan {
+    tcvn_head_cfg cfg;
+    std::vector<Slot> slots;
+    std::vector<float*> data, grad;
+    int cw, ca, ew, eb, ow, ob, dec_width;
+    HBn cn;
+    std::vector<HLayer> layers;
+    std::vector<HDec> dec;
+    bool bound = false;
+    uint64_t last_seed = 0; int last_train = 0;
+
+    explicit HeadPlan(const tcvn_head_cfg& c);
+    int add_slot(const std::string& name, long numel, int kind);
+    HBn add_bn(const std::string& p, int c);
+    int bind(void* const* d, void* const* g);
+    void layout(int B, int P, int nP, HLayout& L) const;
+    int forward(int B, int P, int nP, const float* rows, const int32_t* tok_row, float* ev_logits, float* pr_logits, char* ws,
+                long ws_bytes, int train, uint64_t seed, hipStream_t st);
+    int loss(int B, int P, const float* ev_logits, const float* pr_logits, const int64_t* et, const int8_t* pt, float* losses,
+             float* accs, float* dEv, float* dPr, hipStream_t st);
+    int backward(int B, int P, int nP, const float* rows, const int32_t* tok_row, const float* dEv, const float* dPr, float* d_rows,
+                 char* ws, long ws_bytes, hipStream_t st);
+};
+
+}  // namespace tcvn

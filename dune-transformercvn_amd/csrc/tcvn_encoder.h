@@ -1,0 +1,44 @@
+// Launch interface of the token-path kernels (encoder.hip).
+#pragma once
+#include "tcvn_common.h"
+
+namespace tcvn {
+
+int gather_tokens(const float* C, const int* tok_row, float* X, int B, int S, int D, hipStream_t st);
+int scatter_tokens_bwd(const float* dX, const int* tok_row, float* dC, int B, int S, int D, hipStream_t st);
+int mask_rows(const float* X, const int* tok_row, float* Y, int B, int S, int D, hipStream_t st);
+// out[(b*P+p)*C + c] = in[(p*B+b)*C + c]  (to_batch_major != 0) or the inverse
+int permute_rows(const float* in, float* out, int B, int P, int C, int to_batch_major, hipStream_t st);
+
+struct AttnArgs {
+    const float* qkv; const int* tok_row; float* probs; float* ctx;
+    int B, S, H, hd; float drop_p; uint64_t seed; uint32_t stream_id;
+};
+int attn_fwd(const AttnArgs& a, hipStream_t st);
+struct AttnBwdArgs {
+    const float* qkv; const float* probs; const float* dctx; float* dqkv;
+    int B, S, H, hd; float drop_p; uint64_t seed; uint32_t stream_id;
+};
+int attn_bwd(const AttnBwdArgs& a, hipStream_t st);
+
+struct AddLnArgs {
+    const float* X; const float* R; const float *gamma, *beta; float* Y; float* XH; float* rstd;
+    int T, D; float eps; float drop_p; uint64_t seed; uint32_t stream_id;
+};
+int add_ln_fwd(const AddLnArgs& a, hipStream_t st);
+struct AddLnBwdArgs {
+    const float* dY; const float* XH; const float* rstd; const float* gamma; float* dX; float* dR; float *dgamma, *dbeta;
+    int T, D; float drop_p; uint64_t seed; uint32_t stream_id;
+};
+int add_ln_bwd(const AddLnBwdArgs& a, hipStream_t st);
+
+int act_fwd(const float* X, float* Y, long n, int gelu, float drop_p, uint64_t seed, uint32_t sid, hipStream_t st);
+int act_bwd(const float* X, const float* dY, float* dX, long n, int gelu, float drop_p, uint64_t seed, uint32_t sid, hipStream_t st);
+int add_inplace(float* dst, const float* src, long n, hipStream_t st);
+
+int focal_i64(const float* logits, const int64_t* targets, int rows, int C, float gamma, float weight, float* dlogits, float* out,
+              hipStream_t st);
+int focal_i8(const float* logits, const int8_t* targets, int rows, int C, float gamma, float weight, float* dlogits, float* out,
+             hipStream_t st);
+
+}  // namespace tcvn

@@ -60,12 +60,14 @@ def _load():
     sig("tcvn_head_bind", i32, vp, P(vp), P(vp))
     sig("tcvn_head_workspace_bytes", i64, vp, i32, i32, i32)
     sig("tcvn_head_forward", i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, i64, i32, u64, vp)
-    sig("tcvn_head_loss", i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp)
-    sig("tcvn_head_backward", i32, vp, i32, i32, i32, vp, vp, f32, vp, vp, i64, vp)
+    sig("tcvn_head_loss", i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp)
+    sig("tcvn_head_backward", i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp)
+    sig("tcvn_focal_loss", i32, vp, vp, i32, i32, f32, f32, vp, vp, vp)
     return lib
 
 
 EXPORTS = [
+    "tcvn_focal_loss",
     "tcvn_version", "tcvn_densenet_create", "tcvn_densenet_destroy", "tcvn_densenet_num_slots", "tcvn_densenet_slot",
     "tcvn_densenet_bind", "tcvn_densenet_workspace_bytes", "tcvn_densenet_forward", "tcvn_densenet_backward",
     "tcvn_densenet_tap", "tcvn_head_create", "tcvn_head_destroy", "tcvn_head_num_slots", "tcvn_head_slot", "tcvn_head_bind",

@@ -124,3 +124,83 @@ class DenseNetEngine(_Plan):
         dt = torch.float32 if es.value == 4 else torch.bfloat16
         raw = self._ws[off.value: off.value + n.value * h.value * w.value * ld.value * es.value].view(dt)
         return raw.view(n.value, h.value, w.value, ld.value)[..., :c.value]
+
+
+class HeadEngine(_Plan):
+    """Combined embedding + transformer encoder + decoders + focal loss (tcvn_head_* in include/tcvn_hip.h)."""
+    _prefix = "head"
+
+    def __init__(self, hidden_dim: int, heads: int, n_layers: int, in_dim: int, event_classes: int, prong_classes: int,
+                 dec_dims, dec_out_in: int, gelu: bool, norm_first: bool, dropout: float, gamma: float, event_weight: float):
+        super().__init__()
+        cfg = _lib.HeadCfg()
+        cfg.hidden_dim, cfg.heads, cfg.n_layers, cfg.in_dim = hidden_dim, heads, n_layers, in_dim
+        cfg.event_classes, cfg.prong_classes = event_classes, prong_classes
+        cfg.n_dec = len(dec_dims)
+        for i, d in enumerate(dec_dims):
+            cfg.dec_dims[i] = d
+        cfg.dec_out_in, cfg.gelu, cfg.norm_first = dec_out_in, int(gelu), int(norm_first)
+        cfg.dropout_modules = int(dropout > 0.0)
+        cfg.dropout, cfg.gamma, cfg.event_weight = dropout, gamma, event_weight
+        self.cfg = cfg
+        check(lib.tcvn_head_create(C.byref(cfg), C.byref(self.handle)), "head_create")
+        self._shape = (0, 0, 0)
+
+    def forward(self, rows: torch.Tensor, tok_row: torch.Tensor, batch: int, max_prongs: int, n_prongs: int, train: bool,
+                seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        assert rows.dtype == torch.float32 and rows.is_contiguous() and rows.shape == (batch + n_prongs, self.cfg.in_dim)
+        assert tok_row.dtype == torch.int32 and tok_row.is_contiguous() and tok_row.shape == (batch, 1 + max_prongs)
+        ws = self.workspace(lib.tcvn_head_workspace_bytes(self.handle, batch, max_prongs, n_prongs), rows.device)
+        ev = torch.empty(batch, self.cfg.event_classes, device=rows.device)
+        pr = torch.empty(batch, max_prongs, self.cfg.prong_classes, device=rows.device)
+        self._shape = (batch, max_prongs, n_prongs)
+        check(lib.tcvn_head_forward(self.handle, batch, max_prongs, n_prongs, _ptr(rows), _ptr(tok_row), _ptr(ev), _ptr(pr),
+                                    _ptr(ws), ws.numel(), int(train), C.c_uint64(seed), _stream_ptr()), "head_forward")
+        return ev, pr
+
+    def loss(self, ev: torch.Tensor, pr: torch.Tensor, event_targets: torch.Tensor, prong_targets: torch.Tensor):
+        """-> (losses[3] = total/event/prong, accs[2], d_event_logits, d_prong_logits), all on the device."""
+        batch, max_prongs = pr.shape[0], pr.shape[1]
+        assert ev.is_contiguous() and pr.is_contiguous() and ev.dtype == torch.float32 and pr.dtype == torch.float32
+        assert event_targets.dtype == torch.int64 and prong_targets.dtype == torch.int8
+        assert event_targets.is_contiguous() and prong_targets.is_contiguous() and prong_targets.shape == (batch, max_prongs)
+        losses = torch.empty(3, device=ev.device)
+        accs = torch.empty(6, device=ev.device)
+        d_ev, d_pr = torch.empty_like(ev), torch.empty_like(pr)
+        check(lib.tcvn_head_loss(self.handle, batch, max_prongs, _ptr(ev), _ptr(pr), _ptr(event_targets), _ptr(prong_targets),
+                                 _ptr(losses), _ptr(accs), _ptr(d_ev), _ptr(d_pr), _stream_ptr()), "head_loss")
+        return losses, accs[:2], d_ev, d_pr
+
+    def backward(self, rows: torch.Tensor, tok_row: torch.Tensor, d_ev: torch.Tensor, d_pr: torch.Tensor) -> torch.Tensor:
+        batch, max_prongs, n_prongs = self._shape
+        assert d_ev.is_contiguous() and d_pr.is_contiguous() and d_ev.dtype == torch.float32 and d_pr.dtype == torch.float32
+        d_rows = torch.empty_like(rows)
+        ws = self._ws
+        check(lib.tcvn_head_backward(self.handle, batch, max_prongs, n_prongs, _ptr(rows), _ptr(tok_row), _ptr(d_ev), _ptr(d_pr),
+                                     _ptr(d_rows), _ptr(ws), ws.numel(), _stream_ptr()), "head_backward")
+        return d_rows
+
+
+class _FocalRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits: torch.Tensor, targets: torch.Tensor, gamma: float):
+        lg = logits.contiguous().float()
+        tg = targets.to(lg.device, torch.int64).contiguous()
+        d = torch.empty_like(lg)
+        out = torch.empty(2, device=lg.device)
+        check(lib.tcvn_focal_loss(_ptr(lg), _ptr(tg), lg.shape[0], lg.shape[1], float(gamma), 1.0, _ptr(d), _ptr(out),
+                                  _stream_ptr()), "focal_loss")
+        ctx.save_for_backward(d)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return d * g, None, None
+
+
+def focal_rows(logits: torch.Tensor, targets: torch.Tensor, gamma: float) -> torch.Tensor:
+    """mean_i(-log p_t (1-p_t)^gamma) over the rows of one logit matrix, on the HIP focal kernel."""
+    if not logits.is_cuda:
+        raise RuntimeError("transformercvn (MI355X build): the focal loss runs on the GPU only")
+    return _FocalRows.apply(logits, targets, gamma)

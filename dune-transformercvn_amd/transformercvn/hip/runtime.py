@@ -1,0 +1,240 @@
+"""Host-side runtime of the fused network step.
+
+Owns (a) the flat parameter / gradient / buffer arenas the ``nn.Parameter`` objects are views of -- one contiguous fp32
+gradient buffer is what the data-parallel all-reduce works on --, (b) the native plans (two DenseNet engines + the token
+path engine) bound to those views, and (c) the autograd glue: one ``torch.autograd.Function`` whose backward launches the
+HIP backward and accumulates straight into the arena (parameter gradients never travel through autograd).
+
+PyTorch supplies device memory, the current stream and (optionally) torch.distributed; all arithmetic is in libtcvn_hip.so.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from .engine import DenseNetEngine, HeadEngine
+from .pixels import SparsePixels
+from ..network.layers.packed_data import token_rows
+
+PRECISIONS = {"fp32": _lib.MODE_F32, "f32": _lib.MODE_F32, "32": _lib.MODE_F32, "bf16": _lib.MODE_BF16, "16": _lib.MODE_BF16}
+
+
+class _FusedStep(torch.autograd.Function):
+    """(anchor) -> (event_logits, prong_logits).  The anchor is a dummy leaf that keeps the node in the graph."""
+
+    @staticmethod
+    def forward(ctx, anchor: Tensor, runtime: "HipRuntime", state: dict):
+        ctx.runtime, ctx.state = runtime, state
+        ev, pr = state["event_logits"], state["prong_logits"]
+        return ev, pr
+
+    @staticmethod
+    def backward(ctx, d_ev: Tensor, d_pr: Tensor):
+        ctx.runtime._backward(ctx.state, d_ev, d_pr)
+        return None, None, None
+
+
+class _FocalLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ev: Tensor, pr: Tensor, runtime: "HipRuntime", event_targets: Tensor, prong_targets: Tensor):
+        losses, accs, d_ev, d_pr = runtime.head.loss(ev.contiguous(), pr.contiguous(), event_targets, prong_targets)
+        ctx.save_for_backward(d_ev, d_pr)
+        out = (losses[0], losses[1], losses[2], accs[0], accs[1])
+        ctx.mark_non_differentiable(*out[1:])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_total, *_):
+        d_ev, d_pr = ctx.saved_tensors
+        return d_ev * g_total, d_pr * g_total, None, None, None
+
+
+class HipRuntime:
+    def __init__(self, network: nn.Module, options, pixel_shape: Tuple[int, int], precision: str = "fp32", seed: int = 0):
+        self.network = network
+        self.options = options
+        self.mode = PRECISIONS[str(precision).lower()]
+        self.pixel_shape = tuple(pixel_shape)
+        self.seed = seed
+        self.step = 0
+        pe = network.prong_embedding
+        if not (options.linear_batch_norm and options.linear_prelu_activation):
+            raise NotImplementedError("the MI355X path implements LinearBlock as Linear-BatchNorm1d-PReLU (both option files)")
+        if options.one_hot_pixels:
+            raise NotImplementedError("one_hot_pixels is not on the MI355X hot path (false in both option files)")
+        if not options.disable_smart_features:
+            raise NotImplementedError("smart prong features are not on the MI355X hot path (disabled in both option files)")
+        H, W = self.pixel_shape
+        self.ev_engine = pe.event_pixel_embedding.hip_engine(self.mode, H, W)
+        self.pr_engine = pe.prong_pixel_embedding.hip_engine(self.mode, H, W)
+        dec = network.prong_decoder
+        self.head = HeadEngine(options.hidden_dim, options.num_attention_heads, options.num_encoder_layers,
+                               pe.feature_embedding_dim + pe.pixel_embedding_dim + pe.position_embedding_dim,
+                               network.event_decoder.hidden_layer.out_features, dec.output_dim, dec.widths,
+                               dec.output_layer.in_features, options.transformer_activation == "gelu",
+                               bool(options.transformer_norm_first), float(options.dropout), float(options.loss_gamma),
+                               float(options.event_prong_loss_proportion))
+        self.anchor: Optional[Tensor] = None
+        self.flat_param = self.flat_grad = self.flat_buf = None
+        self._sig = None
+        self._grad_views: List[Tensor] = []
+        self._bn_counters: List[Tensor] = []
+        self.grad_ready_hook = None          # called as hook(tag) when a gradient segment is final ("head", "event", "prong")
+        self.segments: Dict[str, Tuple[int, int]] = {}
+
+    # ---------------------------------------------------------------------------------------------------------------
+    # flat arenas
+    # ---------------------------------------------------------------------------------------------------------------
+    def _needs_rebind(self) -> bool:
+        ps = [p for p in self.network.parameters()]
+        if self.flat_param is None or not ps:
+            return True
+        first, last = ps[0], ps[-1]
+        return (first.device != self.flat_param.device or first.data_ptr() != self._sig[0] or last.data_ptr() != self._sig[1])
+
+    def ensure_bound(self):
+        if not self._needs_rebind():
+            return
+        net = self.network
+        params = [(n, p) for n, p in net.named_parameters()]
+        dev = params[0][1].device
+        if dev.type != "cuda":
+            raise RuntimeError("transformercvn (MI355X build): parameters must live on the GPU; there is no CPU fallback")
+        total = sum(p.numel() for _, p in params)
+        flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self._grad_views = []
+        offsets = {}
+        for n, p in params:
+            k = p.numel()
+            flat_p[off:off + k].copy_(p.detach().reshape(-1).float())
+            p.data = flat_p[off:off + k].view(p.shape)
+            gv = flat_g[off:off + k].view(p.shape)
+            if p.requires_grad:
+                p.grad = gv
+            self._grad_views.append(gv)
+            offsets[n] = (off, k)
+            off += k
+        bufs = [(n, b) for n, b in net.named_buffers() if b.is_floating_point()]
+        flat_b = torch.empty(sum(b.numel() for _, b in bufs), dtype=torch.float32, device=dev)
+        off = 0
+        for n, b in bufs:
+            k = b.numel()
+            flat_b[off:off + k].copy_(b.reshape(-1).float())
+            b.data = flat_b[off:off + k].view(b.shape)
+            off += k
+        self.flat_param, self.flat_grad, self.flat_buf = flat_p, flat_g, flat_b
+        ps = [p for _, p in params]
+        self._sig = (ps[0].data_ptr(), ps[-1].data_ptr())
+        self._params = ps
+        # gradient segments for overlapped all-reduce: parameters are laid out in registration order
+        def span(prefix):
+            keys = [k for k in offsets if k.startswith(prefix)]
+            lo = min(offsets[k][0] for k in keys)
+            hi = max(offsets[k][0] + offsets[k][1] for k in keys)
+            return lo, hi
+        self.segments = {"prong": span("prong_embedding.prong_pixel_embedding."),
+                         "event": span("prong_embedding.event_pixel_embedding.")}
+        # bind the native plans to the views
+        named_p = dict(net.named_parameters())
+        named_b = {n: b for n, b in net.named_buffers() if b.is_floating_point()}
+        grads = {n: g for (n, _), g in zip(params, self._grad_views)}
+
+        def sub(prefix):
+            d = {k[len(prefix):]: v.detach() for k, v in named_p.items() if k.startswith(prefix)}
+            d.update({k[len(prefix):]: v for k, v in named_b.items() if k.startswith(prefix)})
+            g = {k[len(prefix):]: v for k, v in grads.items() if k.startswith(prefix)}
+            return d, g
+        d, g = sub("prong_embedding.event_pixel_embedding.")
+        self.ev_engine.bind(d, g)
+        d, g = sub("prong_embedding.prong_pixel_embedding.")
+        self.pr_engine.bind(d, g)
+        d, g = sub("")
+        self.head.bind(d, g)
+        self.anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self._pos = named_p["prong_embedding.event_position_embedding"]
+        self._pos_grad = grads["prong_embedding.event_position_embedding"]
+        pe = net.prong_embedding
+        ran = [m for mod in (pe.event_pixel_embedding, pe.prong_pixel_embedding, pe.combined_embedding, net.prong_decoder)
+               for m in mod.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
+        self._bn_counters = [m.num_batches_tracked for m in ran]
+
+    def zero_grad(self):
+        """Zero the gradient arena in one memset and (re)attach the per-parameter views."""
+        self.ensure_bound()
+        self.flat_grad.zero_()
+        for p, gv in zip(self._params, self._grad_views):
+            if p.requires_grad and p.grad is not gv:
+                p.grad = gv
+
+    def _reattach_grads(self):
+        stale = False
+        for p, gv in zip(self._params, self._grad_views):
+            if p.requires_grad and p.grad is not gv:
+                if p.grad is not None:
+                    gv.add_(p.grad)            # someone accumulated into a foreign tensor: fold it in
+                else:
+                    stale = True
+                p.grad = gv
+        return stale
+
+    # ---------------------------------------------------------------------------------------------------------------
+    # forward / backward
+    # ---------------------------------------------------------------------------------------------------------------
+    def forward(self, features: Tensor, extra: Tensor, event_px: SparsePixels, event_mask: Tensor, prong_px: SparsePixels,
+                prong_mask: Tensor, counts: Optional[Tuple[int, int]] = None) -> Tuple[Tensor, Tensor]:
+        self.ensure_bound()
+        net, opt = self.network, self.options
+        pe = net.prong_embedding
+        dev = self.flat_param.device
+        training = net.training
+        B, P = prong_mask.shape
+        n_prongs = int(counts[1]) if counts is not None else int(prong_mask.sum().item())
+        prong_mask = prong_mask.to(dev)
+        event_px.count, prong_px.count = B, n_prongs
+        tok_row = token_rows(prong_mask, B)
+        feat, pix, pos = pe.feature_embedding_dim, pe.pixel_embedding_dim, pe.position_embedding_dim
+        in_dim = feat + pix + pos
+        seed = (self.seed * 1000003 + self.step) & 0x7FFFFFFFFFFFFFFF
+        self.step += 1
+        with torch.no_grad():
+            rows = torch.zeros(B + n_prongs, in_dim, device=dev)
+            rows[:, feat + pix:] = self._pos            # prongs also get the *event* position embedding (reference quirk)
+            self.ev_engine.forward(event_px.coords, event_px.values, B, rows[:B, :feat + pix], training, seed ^ 0x1111,
+                                   event_px.value_mode, event_px.noise_std if training else 0.0)
+            self.pr_engine.forward(prong_px.coords, prong_px.values, n_prongs, rows[B:, feat:feat + pix], training,
+                                   seed ^ 0x2222, prong_px.value_mode, prong_px.noise_std if training else 0.0)
+            ev, pr = self.head.forward(rows, tok_row, B, P, n_prongs, training, seed ^ 0x3333)
+            if training:
+                torch._foreach_add_(self._bn_counters, 1)
+        if not (training and torch.is_grad_enabled()):
+            return ev, pr
+        state = dict(rows=rows, tok_row=tok_row, B=B, P=P, n_prongs=n_prongs, event_logits=ev, prong_logits=pr,
+                     feat=feat, pix=pix)
+        return _FusedStep.apply(self.anchor, self, state)
+
+    def _backward(self, st: dict, d_ev: Tensor, d_pr: Tensor):
+        if self._reattach_grads():
+            pass                                     # grads were set to None by zero_grad(set_to_none=True): views re-attached
+        B, feat, pix = st["B"], st["feat"], st["pix"]
+        d_rows = self.head.backward(st["rows"], st["tok_row"], d_ev.contiguous(), d_pr.contiguous())
+        self._pos_grad.add_(d_rows[:, feat + pix:].sum(0, keepdim=True))
+        if self.grad_ready_hook:
+            self.grad_ready_hook("head")
+        self.ev_engine.backward(d_rows[:B, :feat + pix])
+        if self.grad_ready_hook:
+            self.grad_ready_hook("event")
+        self.pr_engine.backward(d_rows[B:, feat:feat + pix])
+        if self.grad_ready_hook:
+            self.grad_ready_hook("prong")
+
+    def loss(self, ev: Tensor, pr: Tensor, event_targets: Tensor, prong_targets: Tensor):
+        """-> (total, event_loss, prong_loss, event_accuracy, prong_accuracy) as 0-d device tensors; total is differentiable."""
+        dev = ev.device
+        et = event_targets.to(dev, torch.int64).contiguous()
+        pt = prong_targets.to(dev, torch.int8).contiguous()
+        return _FocalLoss.apply(ev, pr, self, et, pt)

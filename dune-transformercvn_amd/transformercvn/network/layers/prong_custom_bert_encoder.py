@@ -1,0 +1,20 @@
+"""Transformer encoder over the (event + prongs) token set (reference: layers/prong_custom_bert_encoder.py:29-75).
+
+``self.encoder`` is a stock ``nn.TransformerEncoder`` used purely as a parameter holder so that the state_dict keys
+(``encoder.layers.<l>.self_attn.in_proj_weight`` ...) and the default initialisation match the reference; note the
+reference passes ``hidden_dim`` as ``dim_feedforward``.  Execution: csrc/encoder.hip via the head engine."""
+import warnings
+
+from torch import nn
+
+from transformercvn.options import Options
+
+
+class ProngCustomBertEncoder(nn.Module):
+    def __init__(self, options: Options, hidden_dim: int, num_heads: int, dropout: float, activation: str, norm_first: bool):
+        super().__init__()
+        self.options = options
+        layer = nn.TransformerEncoderLayer(hidden_dim, num_heads, hidden_dim, dropout, activation, norm_first=norm_first)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            self.encoder = nn.TransformerEncoder(layer, options.num_encoder_layers)

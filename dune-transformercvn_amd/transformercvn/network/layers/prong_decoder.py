@@ -1,0 +1,12 @@
+"""Event classification head: one Linear(hidden_dim -> classes) (reference: layers/prong_decoder.py:7-16)."""
+from torch import nn
+
+from transformercvn.options import Options
+
+
+class ProngDecoder(nn.Module):
+    def __init__(self, options: Options, output_dim: int, hidden_dim_factor: int = 1):
+        super().__init__()
+        self.options = options
+        self.hidden_dim_factor = hidden_dim_factor
+        self.hidden_layer = nn.Linear(hidden_dim_factor * options.hidden_dim, output_dim)

@@ -1,0 +1,121 @@
+"""Lightning-module level of the hot path (reference: trainers/neutrino_full_base_trainer.py:20-230): feature
+normalisation, pixel preprocessing, network call, softmax focal loss, training/validation steps."""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+from transformercvn.options import Options
+from transformercvn.network.trainers.neutrino_base import NeutrinoBase
+from transformercvn.dataset.minkowski_dataset import MinkowskiDataset, MinkowskiCollection
+from transformercvn.network.trainers.metrics import make_metrics
+
+
+class NeutrinoFullBaseTrainer(NeutrinoBase, ABC):
+    @abstractmethod
+    def create_network(self, options: Options, features_dim: int, extra_dim: int, pixel_dim: int, num_prong_classes: int,
+                       num_event_classes: int):
+        raise NotImplementedError()
+
+    @abstractmethod
+    def preprocess_pixels(self, pixel_coords: Tensor, pixel_values: Tensor, image_size: Tuple[int, ...]):
+        raise NotImplementedError()
+
+    def __init__(self, options: Options):
+        super().__init__(options)
+        ds = self.training_dataset
+        self.hidden_dim = options.hidden_dim
+        self.network = self.create_network(options, ds.num_features, ds.num_extra, ds.pixel_features, ds.num_prong_classes,
+                                           ds.num_event_classes)
+        self.network.pixel_shape = tuple(ds.pixel_shape)
+        self.beta = 1 - 1 / len(ds)
+        self.gamma = options.loss_gamma
+        self.event_loss_scale = options.event_prong_loss_proportion
+        self.prong_loss_scale = 1.0 - options.event_prong_loss_proportion
+        (self.event_accuracy, self.prong_accuracy, self.event_auc, self.prong_auc) = make_metrics(ds.num_event_classes,
+                                                                                                 ds.num_prong_classes)
+
+    @property
+    def dataset(self):
+        return MinkowskiDataset
+
+    @property
+    def dataloader_options(self):
+        return {"drop_last": True, "batch_size": self.options.batch_size, "num_workers": self.options.num_dataloader_workers,
+                "collate_fn": MinkowskiCollection()}
+
+    # ---- forward ---------------------------------------------------------------------------------------------------
+    def forward(self, features: Tensor, extra: Tensor, event_coords: Tensor, event_values: Tensor, event_mask: Tensor,
+                prong_coords: Tensor, prong_values: Tensor, prong_mask: Tensor, counts=None) -> Tuple[Tensor, Tensor]:
+        """-> (event_logits [B, Ce], prong_logits [B, P, Cp]) (reference :90-116).  Inputs are borrowed, never mutated."""
+        dev = event_values.device
+        if torch.is_tensor(self.mean) and features.numel() and not self.options.disable_smart_features:
+            features = features.clone()
+            features[prong_mask] = (features[prong_mask] - self.mean) / self.std
+            extra = (extra - self.extra_mean) / self.extra_std
+        shape = self.training_dataset.pixel_shape
+        event_pixels = self.preprocess_pixels(event_coords, event_values, shape)
+        prong_pixels = self.preprocess_pixels(prong_coords, prong_values, shape)
+        return self.network(features, extra, event_pixels, event_mask, prong_pixels, prong_mask, counts)
+
+    def shared_step(self, batch):
+        (features, extra, ev_c, ev_v, ev_m, pr_c, pr_v, pr_m, ev_t, pr_t) = batch[:10]
+        counts = batch[10] if len(batch) > 10 else None               # optional host-side (max_prongs, n_prongs): avoids syncs
+        if counts is not None:
+            width, n_prongs = int(counts[0]), int(counts[1])
+        else:
+            per_event = pr_m.sum(1)
+            width, n_prongs = int(per_event.max()), int(per_event.sum())
+        features = features[:, :width].contiguous()
+        pr_m = pr_m[:, :width].contiguous()
+        pr_t = pr_t[:, :width].contiguous()
+        return (ev_t, pr_t, *self.forward(features, extra, ev_c, ev_v, ev_m, pr_c, pr_v, pr_m, (features.shape[0], n_prongs)))
+
+    def loss(self, logits: Tensor, targets: Tensor) -> Tensor:
+        """Softmax focal loss mean_i(-log p_t (1 - p_t)^gamma), cross-entropy for gamma == 0 (reference :148-160) for one
+        logit matrix, on the HIP focal kernel."""
+        rt = self.network.hip_runtime()
+        from transformercvn.hip.engine import focal_rows
+        return focal_rows(logits, targets, float(self.gamma))
+
+    def losses(self, event_logits, prong_logits, event_targets, prong_targets):
+        """(total, event_loss, prong_loss, event_accuracy, prong_accuracy) from the fused loss kernel (:162-183)."""
+        return self.network.hip_runtime().loss(event_logits, prong_logits, event_targets, prong_targets)
+
+    def training_step(self, batch, batch_idx):
+        event_targets, prong_targets, event_logits, prong_logits = self.shared_step(batch)
+        total, event_loss, prong_loss, event_acc, prong_acc = self.losses(event_logits, prong_logits, event_targets, prong_targets)
+        self.log("prong_loss", prong_loss)
+        self.log("event_loss", event_loss)
+        self.log("train_loss", total)
+        self.log("train_event_accuracy", event_acc)
+        self.log("train_prong_accuracy", prong_acc)
+        return total
+
+    def validation_step(self, batch, batch_idx):
+        event_targets, prong_targets, event_logits, prong_logits = self.shared_step(batch)
+        valid = prong_targets.to(prong_logits.device) >= 0
+        prong_probs = torch.softmax(prong_logits[valid], dim=-1)
+        event_probs = torch.softmax(event_logits, dim=-1)
+        pt = prong_targets.to(prong_logits.device)[valid].long()
+        et = event_targets.to(event_logits.device)
+        self.prong_accuracy.update(prong_probs, pt)
+        self.event_accuracy.update(event_probs, et)
+        self.prong_auc.update(prong_probs, pt)
+        self.event_auc.update(event_probs, et)
+
+    def validation_epoch_end(self, outputs) -> None:
+        ea, pa = self.event_accuracy.compute(), self.prong_accuracy.compute()
+        eu, pu = self.event_auc.compute(), self.prong_auc.compute()
+        for name, value in (("val_epoch_accuracy", (pa + ea) / 2), ("event_epoch_accuracy", ea), ("prong_epoch_accuracy", pa),
+                            ("val_epoch_AUC", (eu + pu) / 2), ("event_epoch_AUC", eu), ("prong_epoch_AUC", pu)):
+            self.log(name, value, sync_dist=True)
+        for m in (self.event_accuracy, self.prong_accuracy, self.event_auc, self.prong_auc):
+            m.reset()
+
+    # Lightning hook: zero the flat gradient arena with one memset instead of per-parameter set_to_none
+    def optimizer_zero_grad(self, *args, **kwargs):
+        self.network.hip_runtime().zero_grad()

@@ -108,16 +108,23 @@ int64_t tcvn_head_workspace_bytes(const tcvn_head* p, int batch, int max_prongs,
 int tcvn_head_forward(tcvn_head* p, int batch, int max_prongs, int n_prongs, const float* rows, const int32_t* tok_row,
                       float* event_logits, float* prong_logits, void* workspace, int64_t workspace_bytes, int train,
                       uint64_t seed, void* stream);
-/* Softmax focal loss on the logits of the last forward (+ its gradient, kept in the workspace).
+/* Softmax focal loss and its gradient w.r.t. the logits (trainers/neutrino_full_base_trainer.py:148-177):
  * event_targets [batch] int64, prong_targets [batch, max_prongs] int8 (-1 = padding).
- * losses[3] (device, fp32) = {total, event, prong}; accs[2] = {event accuracy, prong accuracy}. */
+ * losses[3] (device, fp32) = {total, event, prong}; accs[6]: {event accuracy, prong accuracy} + 4 floats of scratch;
+ * d_event_logits [batch, event_classes], d_prong_logits [batch, max_prongs, prong_classes] = d(total)/d(logits). */
 int tcvn_head_loss(tcvn_head* p, int batch, int max_prongs, const float* event_logits, const float* prong_logits,
-                   const int64_t* event_targets, const int8_t* prong_targets, float* losses, float* accs, void* workspace,
-                   int64_t workspace_bytes, void* stream);
-/* Backward from the loss gradient in the workspace to d_rows [batch + n_prongs, in_dim]; parameter gradients are
- * accumulated into the bound grad pointers. loss_scale multiplies d(total loss). */
+                   const int64_t* event_targets, const int8_t* prong_targets, float* losses, float* accs,
+                   float* d_event_logits, float* d_prong_logits, void* stream);
+/* Backward of the last train-mode forward on the same workspace: logit gradients -> d_rows [batch + n_prongs, in_dim];
+ * parameter gradients are ACCUMULATED into the bound grad pointers. */
 int tcvn_head_backward(tcvn_head* p, int batch, int max_prongs, int n_prongs, const float* rows, const int32_t* tok_row,
-                       float loss_scale, float* d_rows, void* workspace, int64_t workspace_bytes, void* stream);
+                       const float* d_event_logits, const float* d_prong_logits, float* d_rows, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+
+/* Stand-alone softmax focal loss of one logit matrix [rows, classes] (targets int64, < 0 = ignore):
+ * out2 = {mean loss, accuracy}; d_logits = weight * d(mean loss)/d(logits). Single workgroup; rows up to a few thousand. */
+int tcvn_focal_loss(const float* logits, const int64_t* targets, int rows, int classes, float gamma, float weight,
+                    float* d_logits, float* out2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,93 @@
+"""Drop-in Lightning module on the MI355X (HIP path through the C ABI) against the reference's golden vectors and the
+fp64 CPU oracle.  Gate of BASELINE.json: event and prong logits within 1e-3 relative (fp32 mode)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tcvn_oracle as O
+from golden_utils import load_case, train_cfg, rel_err
+from model_utils import build_trainer, to_device
+from test_oracle_golden import grad_close, is_noise_grad
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_GATE = 1e-3          # BASELINE.json north_star
+CASES = ["small_b3", "tutorial_b2p4", "tutorial_ragged"]
+
+
+def _loaded_so():
+    with open("/proc/self/maps") as f:
+        return any("libtcvn_hip.so" in line for line in f)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_eval_logits_match_reference(name):
+    cfg, over, batch, g = load_case(name)
+    model = build_trainer(cfg, O.fill_state(cfg, int(g["weight_seed"])))
+    model.eval()
+    with torch.no_grad():
+        et, pt, ev, pr = model.shared_step(to_device(batch))
+    assert _loaded_so()
+    e1, e2 = rel_err(ev.cpu(), g["eval_event_logits"]), rel_err(pr.cpu(), g["eval_prong_logits"])
+    print(name, "eval logit rel err", e1, e2)
+    assert e1 < LOGIT_GATE and e2 < LOGIT_GATE
+    assert e1 < 5e-5 and e2 < 5e-5           # what fp32 actually achieves
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_step_matches_reference(name):
+    cfg, over, batch, g = load_case(name)
+    cfgt = train_cfg(over)
+    sd = O.fill_state(cfgt, int(g["weight_seed"]))
+    model = build_trainer(cfgt, sd)
+    model.train()
+    rt = model.network.hip_runtime()
+    rt.zero_grad()
+    dbatch = to_device(batch)
+    loss = model.training_step(dbatch, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["train_total_loss"])) < 1e-4 * abs(float(g["train_total_loss"]))
+    assert abs(model.logged["event_loss"].item() - float(g["train_event_loss"])) < 2e-4
+    assert abs(model.logged["prong_loss"].item() - float(g["train_prong_loss"])) < 2e-4
+    # fp64 oracle gradients are the yardstick; the reference's own fp32 gradients sit 1e-3..1e-2 away from them
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    b64 = tuple(t.double() if t.is_floating_point() else t for t in batch)
+    _, (ev64, pr64), g64, ctx64 = O.train_step(sd64, cfgt, b64)
+    named = dict(model.named_parameters())
+    deep = "tutorial" in name
+    worst = 0.0
+    for k, ref in g64.items():
+        mine = named[k].grad
+        assert mine is not None, k
+        mine = mine.detach().cpu().double()
+        if is_noise_grad(k) or ref.abs().max() < 1e-6:
+            assert mine.abs().max().item() < 5e-3, k
+            continue
+        l2 = ((mine - ref).norm() / ref.norm()).item()
+        worst = max(worst, l2)
+        assert l2 < (2e-2 if deep else 2e-3), (k, l2)
+    print(name, "worst relative L2 gradient error vs fp64 oracle", worst)
+    # golden (reference fp32) sentinels with the fp32 noise band
+    for k in [k for k in g if k.startswith("grad:")]:
+        assert grad_close(k[5:], named[k[5:]].grad.cpu().numpy(), g[k], rtol=5e-2 if deep else 6e-3), k
+    # BatchNorm running statistics after the step
+    msd = model.state_dict()
+    for k in [k for k in g if k.startswith("newstat:")]:
+        if k.endswith("num_batches_tracked"):
+            assert int(msd[k[8:]]) == int(g[k])
+        else:
+            assert rel_err(msd[k[8:]].cpu(), g[k]) < 1e-4, k
+    # train-mode logits of the same step
+    model.zero_grad()
+    with torch.no_grad():
+        et, pt, ev, pr = model.shared_step(dbatch)
+    assert rel_err(ev.cpu(), g["train_event_logits"]) < LOGIT_GATE
+    assert rel_err(pr.cpu(), g["train_prong_logits"]) < LOGIT_GATE
+
+
+def test_cpu_tensors_fail_loudly():
+    cfg, over, batch, g = load_case("small_b3")
+    model = build_trainer(cfg, None, device=None)
+    with pytest.raises(RuntimeError):
+        model.shared_step(batch)
