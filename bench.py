@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Headline benchmark: events/s of one forward+loss+backward of the TransformerCVN DenseNet model (BASELINE.json
+config 2: batch 32, 8 prongs/event, 3x400x280 maps) on N MI355X GPUs, one process per GPU, RCCL gradient all-reduce
+overlapped with backward.  Prints ONE JSON line (rank 0).
+
+    python bench.py [--gpus 1 --steps 5 --warmup 2 --precision bf16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "dune-transformercvn_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_IMAGE_FWD_BWD = 14.385e9      # conv+linear MACs x2 of one DenseNet pass fwd+bwd
+PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+
+
+T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress line on stderr (rank 0 only prints the JSON on stdout)"""
+    print(f"[bench +{time.perf_counter() - T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """CPU threads this process may actually use: the affinity mask, capped at the GPU box's 16-core share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def make_batch(batch, prongs, seed, device):
+    from transformercvn.dataset.minkowski_dataset import SyntheticDataset, MinkowskiCollection
+    ds = SyntheticDataset(batch, prongs, seed=seed)
+    b = MinkowskiCollection()([ds[i] for i in range(batch)])
+    n_prongs = int(b[7].sum())
+    width = int(b[7].sum(1).max())
+    dev = tuple(t.to(device) for t in b)
+    return dev + ((width, n_prongs),)
+
+
+def cpu_baseline(threads):
+    """The oracle (CPU restatement of the reference, oracle/tcvn_oracle.py) timed on the host cores: BASELINE config 1
+    shape (B=2, 4 prongs/event, 2-layer encoder), fp32, forward+loss+backward."""
+    from oracle import tcvn_oracle as O
+    torch.set_num_threads(threads)
+    cfg = O.tutorial_config(num_encoder_layers=2)
+    sd = O.fill_state(cfg, 1)
+    batch = O.synthetic_batch([4, 4], 11, cfg)
+    O.train_step(sd, cfg, batch, apply_dropout=True)               # warm-up (oneDNN primitive creation)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.train_step(sd, cfg, batch, apply_dropout=True)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return {"value": round(2.0 / ts[1], 3), "unit": "events/s", "cores": threads, "kind": "port",
+            "sample": "oracle fp32 fwd+loss+bwd, B=2 x 4 prongs (10 maps), 2-layer encoder, median of 3 steps after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--prongs", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from transformercvn.options import Options
+    from transformercvn.network.trainers.neutrino_full_dense_trainer import NeutrinoFullDenseTrainer
+    from transformercvn.hip import _lib
+    from transformercvn.hip.distributed import GradReducer, broadcast_buffers
+
+    opt = Options.load(os.path.join(PKG, "option_files", "tutorial_densenet_synthetic.json"))
+    opt.batch_size, opt.num_gpu, opt.hip_precision, opt.seed = args.batch, world, args.precision, 1234 + rank
+    opt.training_file = f"synthetic:64:{args.prongs}"
+    torch.manual_seed(0)                                            # identical random-init weights on every rank
+    model = NeutrinoFullDenseTrainer(opt).to(dev)
+    model.train()
+    rt = model.network.hip_runtime()
+    rt.ensure_bound()
+    batch = make_batch(args.batch, args.prongs, 1234 + rank, dev)
+    reducer = GradReducer(rt.flat_grad, rt.segments) if world > 1 else None
+    if reducer:
+        rt.grad_ready_hook = reducer.on_ready
+
+    def step():
+        if reducer:
+            broadcast_buffers(rt.flat_buf)
+        rt.zero_grad()
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        if reducer:
+            reducer.finish()
+        return loss
+
+    note(f"model + batch ready (rank {rank}/{world}, {args.precision}); warm-up ...")
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    note("timed steps ...")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    lossv = float(loss)
+
+    note(f"timed {args.steps} steps in {elapsed:.3f}s")
+    roof, kernels = None, None
+    if rank == 0 and not args.no_profile:
+        _lib.lib.tcvn_profile_reset()
+        _lib.lib.tcvn_profile_enable(1)
+        step()
+        torch.cuda.synchronize()
+        _lib.lib.tcvn_profile_enable(0)
+        agg = {}
+        for name, ms, fl, by in _lib.profile_records():
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += ms; a[2] += fl
+        _lib.lib.tcvn_profile_reset()
+        total_ms = sum(a[1] for a in agg.values())
+        kernels = sorted(({"kernel": k, "launches": a[0], "ms": round(a[1], 3), "avg_ms": round(a[1] / a[0], 4),
+                           "tflops": round(a[2] / a[1] / 1e9, 2) if a[1] > 0 else 0.0} for k, a in agg.items()),
+                         key=lambda r: -r["ms"])
+        top = kernels[0]
+        a = agg[top["kernel"]]
+        ach = a[2] / a[1] / 1e9
+        roof = {"bound": "mfma", "kernel": top["kernel"], "launches_per_step": a[0], "avg_launch_ms": round(a[1] / a[0], 4),
+                "flop_per_launch": a[2] / a[0], "achieved": round(ach, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
+                "frac": round(ach / PEAK[args.precision], 4), "traffic": None, "conv_ms_per_step": round(total_ms, 2)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        events = world * args.batch * args.steps
+        value = events / elapsed
+        per_gpu_tflops = (args.batch * (1 + args.prongs) * FLOP_PER_IMAGE_FWD_BWD) / (elapsed / args.steps) / 1e12
+        out = {
+            "metric": "events/sec (fwd+bwd) at batch=32, 8 prongs/event; fraction of MFMA roofline",
+            "value": round(value, 2), "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"TransformerCVN DenseNet [3,6,12,6,3] g32, fwd+loss+bwd, batch {args.batch}/GPU, "
+                                   f"{args.prongs} prongs/event, 3x400x280 maps, 6-layer encoder, dropout 0.1",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "precision": args.precision},
+            "model_tflops_per_gpu": round(per_gpu_tflops, 2),
+            "frac_of_mfma_peak_whole_step": round(per_gpu_tflops / PEAK[args.precision], 4),
+            "loss": round(lossv, 5),
+        }
+        if roof:
+            out["roofline"] = roof
+            out["kernels"] = kernels[:8]
+        if not args.no_cpu_baseline:
+            note("cpu baseline (oracle on host cores) ...")
+            out["cpu_baseline"] = cpu_baseline(host_threads())
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

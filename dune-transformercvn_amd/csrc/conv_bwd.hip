@@ -6,6 +6,7 @@
 // per-channel (P, Q); its true gradient is G + P*X + Q, formed on the fly by the kernels that consume it.  The
 // per-channel sums every BatchNorm backward needs leave the dgrad epilogue as one partial row per workgroup.
 #include "conv_tile.h"
+#include "prof.h"
 
 namespace tcvn {
 
@@ -379,11 +380,17 @@ int conv_dgrad(const ConvDgradArgs& a, hipStream_t st) {
     if (a.M <= 0) return 0;
     if (a.Kp % BK != 0) return -2;
     if (a.nblk != conv_fwd_grid(a.M)) { fprintf(stderr, "tcvn: conv_dgrad nblk mismatch\n"); return -3; }
+    char nm[96];
+    snprintf(nm, sizeof(nm), "k_conv_dgrad<%s,%d,%d>", a.mode == MODE_F32 ? "float" : "bf16", a.dmode, a.N <= 32 ? 32 : a.N <= 64 ? 64 : 128);
+    ProfScope ps(nm, 2.0 * a.M * (double)a.N * ((a.dmode == DG_3X3 ? 9 : 1) * a.e.N), 0.0, st);
     return a.mode == MODE_F32 ? dgrad_mode<float>(a, st) : dgrad_mode<bf16>(a, st);
 }
 
 int conv_wgrad(const ConvWgradArgs& a, hipStream_t st) {
     if (a.fa.M <= 0) return 0;
+    char nm[96];
+    snprintf(nm, sizeof(nm), "k_conv_wgrad<%s,%d,%d>", a.mode == MODE_F32 ? "float" : "bf16", a.fa.amode, a.e.N <= 32 ? 32 : a.e.N <= 64 ? 64 : 128);
+    ProfScope ps(nm, 2.0 * a.fa.M * (double)a.e.N * a.fa.K, 0.0, st);
     return a.mode == MODE_F32 ? wgrad_mode<float>(a, st) : wgrad_mode<bf16>(a, st);
 }
 

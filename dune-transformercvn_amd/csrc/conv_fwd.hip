@@ -12,6 +12,7 @@
 // Workgroups walk M tiles with a grid stride and keep the per-channel statistics in registers across tiles, so one
 // launch writes one partial row per workgroup (deterministic, no atomics).
 #include "conv_tile.h"
+#include "prof.h"
 
 namespace tcvn {
 
@@ -169,6 +170,9 @@ int conv_fwd(const ConvFwdArgs& a, hipStream_t st) {
     if (a.M <= 0) return 0;
     if (a.Kp % BK != 0 || a.Kp < a.K) { fprintf(stderr, "tcvn: conv_fwd bad Kp=%d K=%d\n", a.Kp, a.K); return -2; }
     if (a.part != nullptr && a.nblk != conv_fwd_grid(a.M)) { fprintf(stderr, "tcvn: conv_fwd nblk mismatch\n"); return -3; }
+    char nm[96];
+    snprintf(nm, sizeof(nm), "k_conv_fwd<%s,%d,%d>", a.mode == MODE_F32 ? "float" : "bf16", a.amode, a.N <= 32 ? 32 : a.N <= 64 ? 64 : 128);
+    ProfScope ps(nm, 2.0 * a.M * (double)a.N * a.K, 0.0, st);
     return a.mode == MODE_F32 ? launch_mode<float>(a, st) : launch_mode<bf16>(a, st);
 }
 

@@ -63,10 +63,26 @@ def _load():
     sig("tcvn_head_loss", i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp)
     sig("tcvn_head_backward", i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp)
     sig("tcvn_focal_loss", i32, vp, vp, i32, i32, f32, f32, vp, vp, vp)
+    sig("tcvn_profile_enable", None, i32)
+    sig("tcvn_profile_reset", None)
+    sig("tcvn_profile_count", i32)
+    sig("tcvn_profile_get", i32, i32, C.c_char_p, i32, P(f32), P(C.c_double), P(C.c_double))
     return lib
 
 
+def profile_records():
+    """[(kernel name, ms, flops, bytes)] of the launches recorded since the last reset (blocks until they finished)."""
+    out = []
+    buf = C.create_string_buffer(128)
+    ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+    for i in range(lib.tcvn_profile_count()):
+        check(lib.tcvn_profile_get(i, buf, 128, C.byref(ms), C.byref(fl), C.byref(by)), "profile_get")
+        out.append((buf.value.decode(), ms.value, fl.value, by.value))
+    return out
+
+
 EXPORTS = [
+    "tcvn_profile_enable", "tcvn_profile_reset", "tcvn_profile_count", "tcvn_profile_get",
     "tcvn_focal_loss",
     "tcvn_version", "tcvn_densenet_create", "tcvn_densenet_destroy", "tcvn_densenet_num_slots", "tcvn_densenet_slot",
     "tcvn_densenet_bind", "tcvn_densenet_workspace_bytes", "tcvn_densenet_forward", "tcvn_densenet_backward",

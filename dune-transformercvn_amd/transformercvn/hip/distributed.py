@@ -1,0 +1,61 @@
+"""Data-parallel gradient exchange for the flat gradient arena (reference: Lightning DDPStrategy -> torch DDP bucketed
+all-reduce over NCCL, train.py:123-127; here RCCL over xGMI via torch.distributed).
+
+One process per GPU.  The gradient arena is cut into the segments the backward pass finishes one after the other
+(token path -> event embedder -> prong embedder); each segment's all-reduce(AVG) is issued asynchronously as soon as the
+runtime reports it final, so it overlaps with the rest of backward.  BatchNorm buffers are broadcast from rank 0 before
+every forward like DDP's broadcast_buffers=True; batch statistics stay per rank (the reference does not sync BN).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def segment_plan(total: int, spans: Dict[str, Tuple[int, int]]) -> Dict[str, List[Tuple[int, int]]]:
+    """Map each readiness tag to the [lo, hi) slices of the flat gradient it completes.  'head' owns everything that is
+    neither the event nor the prong embedder span."""
+    (plo, phi), (elo, ehi) = spans["prong"], spans["event"]
+    cuts = sorted([(plo, phi), (elo, ehi)])
+    head, pos = [], 0
+    for lo, hi in cuts:
+        if lo > pos:
+            head.append((pos, lo))
+        pos = hi
+    if pos < total:
+        head.append((pos, total))
+    return {"head": head, "event": [(elo, ehi)], "prong": [(plo, phi)]}
+
+
+class GradReducer:
+    def __init__(self, flat_grad: torch.Tensor, spans: Dict[str, Tuple[int, int]], group=None):
+        self.flat_grad = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.plan = segment_plan(flat_grad.numel(), spans)
+        self.pending = []
+        self.avg = dist.ReduceOp.AVG if (dist.is_initialized() and dist.get_backend(group) == "nccl") else None
+
+    def on_ready(self, tag: str):
+        if self.world == 1:
+            return
+        for lo, hi in self.plan[tag]:
+            seg = self.flat_grad[lo:hi]
+            if self.avg is not None:
+                self.pending.append((dist.all_reduce(seg, op=self.avg, group=self.group, async_op=True), None))
+            else:                                   # gloo (CPU tests): SUM then scale
+                self.pending.append((dist.all_reduce(seg, group=self.group, async_op=True), seg))
+
+    def finish(self):
+        for work, seg in self.pending:
+            work.wait()
+            if seg is not None:
+                seg.div_(self.world)
+        self.pending = []
+
+
+def broadcast_buffers(flat_buf: torch.Tensor, group=None):
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_buf, 0, group=group)

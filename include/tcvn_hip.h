@@ -126,6 +126,16 @@ int tcvn_head_backward(tcvn_head* p, int batch, int max_prongs, int n_prongs, co
 int tcvn_focal_loss(const float* logits, const int64_t* targets, int rows, int classes, float gamma, float weight,
                     float* d_logits, float* out2, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py roofline leg): when enabled, every convolution launch is bracketed by a HIP event pair on
+ * its own stream.  tcvn_profile_get blocks on the record's end event; name is the kernel's template instance, flops the
+ * algorithmic 2*M*N*K of that launch.  Off by default; enable only for a separate, untimed step.
+ * --------------------------------------------------------------------------------------------------------------- */
+void tcvn_profile_enable(int on);
+void tcvn_profile_reset(void);
+int tcvn_profile_count(void);
+int tcvn_profile_get(int i, char* name, int name_cap, float* ms, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif
