@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--prongs", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dump-records", default="", help="write every profiled launch (name, ms, flops) to this JSON file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -150,7 +151,11 @@ def main():
         torch.cuda.synchronize()
         _lib.lib.tcvn_profile_enable(0)
         agg = {}
-        for name, ms, fl, by in _lib.profile_records():
+        records = _lib.profile_records()
+        if args.dump_records:
+            with open(args.dump_records, "w") as f:
+                json.dump(records, f)
+        for name, ms, fl, by in records:
             a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1; a[1] += ms; a[2] += fl
         _lib.lib.tcvn_profile_reset()
