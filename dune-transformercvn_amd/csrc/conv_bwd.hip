@@ -28,7 +28,7 @@ __device__ __forceinline__ void load_eff8(const EffSrc& e, const T* __restrict__
         float t = 0.f;
         if (j < cnt) {
             t = g[j] + e.P[n + j] * x[j] + e.Q[n + j];
-            if (e.drop_p > 0.f) t *= drop_scale(e.drop_p, e.seed, e.stream_id, (uint64_t)m * e.N + n + j);
+            if (e.drop_p > 0.f) t *= drop_scale_mn(e.drop_p, e.seed, e.stream_id, m, n + j, e.N);
         }
         v[j] = t;
     }

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(NT) void k_conv_fwd(const ConvFwdArgs g) {
                     const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                     if (nok && m < g.M) {
                         float v = acc[i][j][e] + b;
-                        if (g.drop_p > 0.f) v *= drop_scale(g.drop_p, g.seed, g.stream_id, (uint64_t)m * g.N + n);
+                        if (g.drop_p > 0.f) v *= drop_scale_mn(g.drop_p, g.seed, g.stream_id, m, n, g.N);
                         const T o = from_f<T>(v);
                         Out[(long)m * g.ldo + g.n_off + n] = o;
                         const stat_t x = (stat_t)to_f<T>(o);
@@ -166,10 +166,13 @@ int conv_fwd_grid(int M) {
     return mtiles < 512 ? mtiles : 512;
 }
 
+int conv_fwd_nblk(const ConvFwdArgs& a) { return conv3x3_tile_ok(a) ? conv3x3_tile_nblk(a) : conv_fwd_grid(a.M); }
+
 int conv_fwd(const ConvFwdArgs& a, hipStream_t st) {
     if (a.M <= 0) return 0;
     if (a.Kp % BK != 0 || a.Kp < a.K) { fprintf(stderr, "tcvn: conv_fwd bad Kp=%d K=%d\n", a.Kp, a.K); return -2; }
-    if (a.part != nullptr && a.nblk != conv_fwd_grid(a.M)) { fprintf(stderr, "tcvn: conv_fwd nblk mismatch\n"); return -3; }
+    if (a.part != nullptr && a.nblk != conv_fwd_nblk(a)) { fprintf(stderr, "tcvn: conv_fwd nblk mismatch\n"); return -3; }
+    if (conv3x3_tile_ok(a)) return conv3x3_fwd_tile(a, st);
     char nm[96];
     snprintf(nm, sizeof(nm), "k_conv_fwd<%s,%d,%d>", a.mode == MODE_F32 ? "float" : "bf16", a.amode, a.N <= 32 ? 32 : a.N <= 64 ? 64 : 128);
     ProfScope ps(nm, 2.0 * a.M * (double)a.N * a.K, 0.0, st);

@@ -157,7 +157,7 @@ __device__ __forceinline__ void load_a8(const ConvFwdArgs& g, const T* __restric
     }
 }
 
-template <typename T> struct StatAcc { typedef float type; };
+template <typename T> struct StatAcc { typedef double type; };   // fp64 partials: order-independent to ~1e-16
 template <> struct StatAcc<float> { typedef double type; };
 
 

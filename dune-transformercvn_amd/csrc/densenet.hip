@@ -113,7 +113,7 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
     L.c0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
     L.D.clear(); L.Y.clear(); L.bstatD.clear(); L.bstatY.clear();
     long max_part = (long)pool0_grid(n, blocks[0].H, blocks[0].W) * cfg.init_ch * 16;
-    max_part = std::max(max_part, (long)conv_fwd_grid(n * Hc * Wc) * cfg.init_ch * 16);
+    max_part = std::max(max_part, 512L * cfg.init_ch * 16);
     long maxY = 0;
     for (const auto& bg : blocks) {
         const long M = (long)n * bg.H * bg.W;
@@ -122,7 +122,7 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
         for (int l = 0; l < bg.L; ++l) { ys.push_back(b.take(M * mid * esz)); bs.push_back(b.take(mid * 16)); }
         L.Y.push_back(ys); L.bstatY.push_back(bs);
         L.bstatD.push_back(b.take((long)bg.ld * 16));
-        max_part = std::max(max_part, (long)conv_fwd_grid((int)M) * std::max(mid, bg.Ctot) * 16);
+        max_part = std::max(max_part, 512L * std::max(mid, bg.Ctot) * 16);   // every conv launcher uses <= 512 workgroups
         maxY = std::max(maxY, M * mid);
     }
     L.bstat0 = b.take((long)cfg.init_ch * 16);
@@ -356,8 +356,9 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 a.mode = mode; a.amode = A_3X3; a.A = ws + L.Y[bi][l]; a.lda = mid; a.M = (int)M; a.N = g; a.K = 9 * mid;
                 a.Kp = e.Kp; a.C = mid; a.H = bg.H; a.W = bg.W; a.sc = t.sc; a.sh = t.sh; a.sl = data[ls.a2];
                 a.Wk = ws + L.wk + e.off; a.bias = data[ls.b2]; a.Out = D; a.ldo = bg.ld; a.n_off = ls.cin;
-                a.part = train ? part : nullptr; a.nblk = conv_fwd_grid((int)M);
+                a.part = train ? part : nullptr;
                 a.drop_p = train ? cfg.dropout : 0.f; a.seed = seed; a.stream_id = (uint32_t)(bi * 64 + l + 1);
+                a.nblk = conv_fwd_nblk(a);
                 if ((rc = conv_fwd(a, st))) return rc;
                 new_c0 = ls.cin; new_n = g; new_nblk = a.nblk; new_ld = g;
             }

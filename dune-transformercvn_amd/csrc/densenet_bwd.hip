@@ -28,7 +28,7 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     for (const auto& bg : blocks) {
         const long M = (long)n * bg.H * bg.W;
         L.G.push_back(b.take(M * bg.ld * esz));
-        bpart = std::max(bpart, (long)conv_fwd_grid((int)M) * std::max(mid, bg.Ctot) * 24);
+        bpart = std::max(bpart, 512L * std::max(mid, bg.Ctot) * 24);
     }
     for (const auto& bg : blocks) L.pqD.push_back(b.take((long)bg.ld * 8));
     long gw = 0;

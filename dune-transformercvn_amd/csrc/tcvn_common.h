@@ -75,6 +75,22 @@ __device__ __forceinline__ float drop_scale(float p, uint64_t seed, uint32_t str
     return rng_uniform(seed, stream, idx) >= p ? 1.f / (1.f - p) : 0.f;
 }
 
+// Dropout mask of a [pixels, N] activation slice: one Philox call yields the four 32-bit words of the group
+// (pixel >> 2, channel n); pixel & 3 selects the word -- kernels that own 4 consecutive pixels of one channel share a call.
+__device__ __forceinline__ uint4 drop_words(uint64_t seed, uint32_t stream, long m, int n, int N) {
+    const uint64_t grp = (uint64_t)(m >> 2) * (uint64_t)N + (uint64_t)n;
+    return philox4((uint32_t)grp, (uint32_t)(grp >> 32), stream, 0x64726f70u, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ float drop_pick(const uint4& w, long m, float p) {
+    const int k = (int)(m & 3);
+    const uint32_t x = k == 0 ? w.x : k == 1 ? w.y : k == 2 ? w.z : w.w;
+    return (x >> 8) * (1.0f / 16777216.0f) >= p ? 1.f / (1.f - p) : 0.f;
+}
+__device__ __forceinline__ float drop_scale_mn(float p, uint64_t seed, uint32_t stream, long m, int n, int N) {
+    if (p <= 0.f) return 1.f;
+    return drop_pick(drop_words(seed, stream, m, n, N), m, p);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

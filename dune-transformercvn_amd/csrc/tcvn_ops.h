@@ -27,7 +27,12 @@ struct ConvFwdArgs {
     float drop_p; uint64_t seed; uint32_t stream_id;
 };
 int conv_fwd(const ConvFwdArgs& a, hipStream_t st);
-int conv_fwd_grid(int M);            // number of M-blocks (== nblk) the launcher will use for M rows
+int conv_fwd_grid(int M);            // number of M-blocks of the generic kernels for M rows (<= 512)
+int conv_fwd_nblk(const ConvFwdArgs& a);   // grid.x (== rows of `part`) conv_fwd will use for these arguments (<= 512)
+// bf16 3x3 fast path on padded LDS tiles (conv3x3_tile.hip)
+bool conv3x3_tile_ok(const ConvFwdArgs& a);
+int conv3x3_tile_nblk(const ConvFwdArgs& a);
+int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm plumbing
