@@ -32,85 +32,111 @@ __device__ __forceinline__ int pix_of(const PadGeom& q, int g, float invWp, floa
     return (img * q.H + (hp - 1)) * q.W + (wp - 1);
 }
 
-// Stage `nrows` padded positions starting at g_first of a [pixels,128] bf16 tensor into the swizzled 256-B-row LDS image,
-// applying y = prelu(x*sc + sh, sl) per channel.  16 threads per row (one 16-B chunk each); rows advance by 16.
-__device__ __forceinline__ void stage_act128(char* img, const bf16* __restrict__ X, const PadGeom& q, int g_first, int nrows,
-                                             const float* __restrict__ sc, const float* __restrict__ sh,
-                                             const float* __restrict__ sl, float invWp, float invHp, int tid) {
-    const int chunk = tid & 15, r0 = tid >> 4;
-    float csc[8], csh[8], csl[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { csc[j] = sc[chunk * 8 + j]; csh[j] = sh[chunk * 8 + j]; csl[j] = sl[chunk * 8 + j]; }
-#pragma unroll 4
-    for (int row = r0; row < nrows; row += 16) {
-        const int m = pix_of(q, g_first + row, invWp, invHp);
-        u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (m >= 0) {
-            const u16x8 v = *reinterpret_cast<const u16x8*>(X + (long)m * 128 + chunk * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(prelu(fmaf(bf2f(v[j]), csc[j], csh[j]), csl[j]));
-        }
-        *reinterpret_cast<u16x8*>(img + off256(row, chunk)) = o;
+// LDS-DMA one padded image (rows [g_first, g_first + nrows4)) of a pre-activated [pixels,128] bf16 tensor into `buf`:
+// every wave-instruction writes 1 KiB = 4 image rows, lane -> (row = lane>>4, slot = lane&15); the XOR swizzle is applied
+// on the SOURCE chunk (slot s of row r holds channel chunk s ^ (r & 15)), padding rows come from a page of zeros.
+__device__ __forceinline__ void dma_image(char* smem_base, int buf_off, const bf16* __restrict__ XA, const char* __restrict__ zeros,
+                                          const int* rowpix, int nrows4, int wave, int lane) {
+    const int rsub = lane >> 4, slot = lane & 15;
+    for (int rg = wave; rg * 4 < nrows4; rg += 4) {
+        const int r = rg * 4 + rsub;
+        const int m = rowpix[r];                       // pixel index of this image row or -1 (table filled a tile ahead)
+        const char* src = m >= 0 ? reinterpret_cast<const char*>(XA + (long)m * 128) + ((slot ^ (r & 15)) << 4)
+                                 : zeros + (slot << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem_base + buf_off + rg * 1024), 16, 0, 0);
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_bf16(const ConvFwdArgs g, int n_img, int ntiles, int swz) {
+// One workgroup per CU (persistent): weights live in registers for the whole launch (72 fragments = 288 VGPRs), two LDS
+// images double-buffer the LDS-DMA of tile t+1 under the 72 MFMAs + epilogue of tile t.
+__global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_bf16(const ConvFwdArgs g, int n_img, int ntiles, int swz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PadGeom q(n_img, g.H, g.W);
-    const int nrows = q.rows();
-    char* img = smem;
-    int* pix = reinterpret_cast<int*>(smem + nrows * 256);
-    double* red = reinterpret_cast<double*>(smem + nrows * 256 + TP * 4);      // [4][32][2]
+    const int nrows4 = (q.rows() + 3) & ~3;
+    const int img_bytes = nrows4 * 256;      // images at byte offsets 0 and img_bytes (kept as offsets: LDS address space)
+    int* tbl = reinterpret_cast<int*>(smem + 2 * nrows4 * 256);               // [3][nrows4] pixel index per image row
+    double* red = reinterpret_cast<double*>(smem + 2 * nrows4 * 256 + 3 * nrows4 * 4);   // [4][32][2]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
-    const bf16* __restrict__ Y = reinterpret_cast<const bf16*>(g.A);
-    const bf16* __restrict__ Wk = reinterpret_cast<const bf16*>(g.Wk);
+    const bf16* __restrict__ YA = reinterpret_cast<const bf16*>(g.Aact);
+    const char* __restrict__ zeros = reinterpret_cast<const char*>(g.zeros);
+    const bf16* __restrict__ Wf = reinterpret_cast<const bf16*>(g.Wfrag) + lane * 8;   // fragment order: 1 KiB per wave load
     bf16* __restrict__ Out = reinterpret_cast<bf16*>(g.Out);
     const int nb = gridDim.x;
     const int lb = swz ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;   // neighbours share an XCD's L2
     const bool nok = r < g.N;
-    const bf16* wrow = Wk + (long)(nok ? r : 0) * g.Kp + 8 * h;
     const float bias = nok ? g.bias[r] : 0.f;
     const bool drop = g.drop_p > 0.f;
+    const uint32_t dkey = drop_key(g.seed, g.stream_id);
+
+    bf16x8_t bw[72];
+#pragma unroll
+    for (int i = 0; i < 72; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + i * 512);
 
     double s1 = 0, s2 = 0;
-    for (int t = lb; t < ntiles; t += nb) {
-        const int g0 = t * TP;
-        __syncthreads();
-        stage_act128(img, Y, q, g0 - q.halo, nrows, g.sc, g.sh, g.sl, invWp, invHp, tid);
-        if (tid < TP) pix[tid] = pix_of(q, g0 + tid, invWp, invHp);
-        __syncthreads();
-
+    auto fill_tbl = [&](int slot, int tile) {
+        for (int rr = tid; rr < nrows4; rr += 256) tbl[slot * nrows4 + rr] = pix_of(q, tile * TP - q.halo + rr, invWp, invHp);
+    };
+    if (lb < ntiles) fill_tbl(0, lb);
+    if (lb + nb < ntiles) fill_tbl(1, lb + nb);
+    __syncthreads();
+    if (lb < ntiles) dma_image(smem, 0, YA, zeros, tbl, nrows4, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0, ts = 0;                                         // image buffer / table slot of the current tile
+    for (int t = lb; t < ntiles; t += nb, cur ^= 1, ts = ts == 2 ? 0 : ts + 1) {
+        const int tn = ts == 2 ? 0 : ts + 1, tnn = tn == 2 ? 0 : tn + 1;
+        if (t + nb < ntiles && !(g.dbg & 1))                     // prefetch the next tile's image under this tile's MFMAs
+            dma_image(smem, (cur ^ 1) * img_bytes, YA, zeros, tbl + tn * nrows4, nrows4, wave, lane);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        asm volatile("s_nop 4" : "+a"(acc));          // accvgpr writes -> first MFMA (inside asm) needs its wait states
         const int lrow0 = wave * 32 + r + q.halo;
+        const int image = cur * img_bytes;
+        // A fragments of tap+1 are read from LDS while the 8 MFMAs of tap run; weights are consumed straight from AGPRs
+        bf16x8_t af[2][8];
+        {
+            const int lr = lrow0 - q.Wp - 1;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                af[0][ks] = *reinterpret_cast<const bf16x8_t*>(smem + image + lr * 256 + (((2 * ks + h) ^ (lr & 15)) << 4));
+        }
+        if (!(g.dbg & 2))
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int lr = lrow0 + (tap / 3 - 1) * q.Wp + (tap % 3 - 1);
-            const char* arow = img + lr * 256;
-            const int sw = lr & 15;
+            if (tap + 1 < 9) {
+                const int lr = lrow0 + ((tap + 1) / 3 - 1) * q.Wp + ((tap + 1) % 3 - 1);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    af[(tap + 1) & 1][ks] =
+                        *reinterpret_cast<const bf16x8_t*>(smem + image + lr * 256 + (((2 * ks + h) ^ (lr & 15)) << 4));
+            }
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(arow + (((2 * ks + h) ^ sw) << 4));
-                bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wrow + tap * 128 + ks * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                // taps 0-6 keep their weights in AGPRs (16 acc + 224), taps 7-8 in arch VGPRs: no register copies
+                if (tap < 7) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af[tap & 1][ks]), "a"(bw[tap * 8 + ks]));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af[tap & 1][ks]), "v"(bw[tap * 8 + ks]));
             }
         }
+        // the MFMAs sit inside asm statements: hipcc pads no hazard for them -- wait out the last MFMA's result latency
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc));
         // epilogue: bias, dropout (one Philox call per 4 consecutive pixels of a channel), store, statistics
         long cur_grp = -1;
-        uint4 words = make_uint4(0, 0, 0, 0);
+        uint32_t bits = 0;
+        const int* px = tbl + ts * nrows4 + q.halo;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int lp = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const int m = pix[lp];
-            if (m >= 0 && nok) {
+            const int m = px[lp];
+            if (m >= 0 && nok && !(g.dbg & 4)) {
                 float v = acc[e] + bias;
                 if (drop) {
-                    if ((m >> 2) != cur_grp) { cur_grp = m >> 2; words = drop_words(g.seed, g.stream_id, m, r, g.N); }
-                    v *= drop_pick(words, m, g.drop_p);
+                    if ((m >> 1) != cur_grp) { cur_grp = m >> 1; bits = drop_bits(dkey, m, r, g.N); }
+                    v *= drop_pick(bits, m, g.drop_p);
                 }
                 const bf16 o = f2bf(v);
                 Out[(long)m * g.ldo + g.n_off + r] = o;
@@ -118,11 +144,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_bf16(const ConvFwdArgs g
                 s1 += x; s2 += x * x;
             }
         }
+        if (t + 2 * nb < ntiles) fill_tbl(tnn, t + 2 * nb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
     if (g.part != nullptr) {
         double a = s1, b = s2;
         a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
-        __syncthreads();
         if (lane < 32) { red[(wave * 32 + lane) * 2] = a; red[(wave * 32 + lane) * 2 + 1] = b; }
         __syncthreads();
         if (tid < g.N) {
@@ -135,8 +163,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_bf16(const ConvFwdArgs g
     }
 }
 
-int tile_grid(long ntiles) {
-    if (ntiles >= 512) return 512;
+size_t fwd_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return 2 * r4 * 256 + 3 * r4 * 4 + 4 * 32 * 16; }
+
+int tile_grid(long ntiles) {            // one persistent workgroup per CU
+    if (ntiles >= 256) return 256;
     if (ntiles >= 8) return (int)(ntiles / 8 * 8);
     return (int)ntiles;
 }
@@ -151,11 +181,12 @@ static bool tile_disabled() {
 
 bool conv3x3_tile_ok(const ConvFwdArgs& a) {
     if (tile_disabled()) return false;
+    if (a.Wfrag == nullptr || (reinterpret_cast<uintptr_t>(a.Wfrag) & 15) || a.Aact == nullptr || a.zeros == nullptr) return false;
     if (a.mode != MODE_BF16 || a.amode != A_3X3 || a.C != 128 || a.lda != 128 || a.N > 32 || a.Kp != 1152) return false;
     if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.Wk) & 15)) return false;
     if (a.M % (a.H * a.W) != 0) return false;
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
-    return q.gtot < (1L << 24) && (long)q.rows() * 256 + TP * 4 + 4 * 32 * 16 <= 160 * 1024;
+    return q.gtot < (1L << 24) && fwd_smem(q) <= 160 * 1024;
 }
 int conv3x3_tile_nblk(const ConvFwdArgs& a) {
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
@@ -166,7 +197,7 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
     const PadGeom q(n_img, a.H, a.W);
     const int ntiles = (int)q.tiles();
     const int nb = tile_grid(ntiles);
-    const size_t smem = (size_t)q.rows() * 256 + TP * 4 + 4 * 32 * 16;
+    const size_t smem = fwd_smem(q);
     static bool attr = false;
     if (!attr) {
         TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_fwd_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -174,7 +205,10 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
         attr = true;
     }
     ProfScope ps("k_conv3x3_fwd_bf16", 2.0 * a.M * (double)a.N * a.K, 0.0, st);
-    hipLaunchKernelGGL(k_conv3x3_fwd_bf16, dim3(nb), dim3(256), smem, st, a, n_img, ntiles, (nb >= 8 && nb % 8 == 0) ? 1 : 0);
+    ConvFwdArgs b = a;
+    static const int dbg = getenv("TCVN_DBG") ? atoi(getenv("TCVN_DBG")) : 0;
+    b.dbg = dbg;
+    hipLaunchKernelGGL(k_conv3x3_fwd_bf16, dim3(nb), dim3(256), smem, st, b, n_img, ntiles, (nb >= 8 && nb % 8 == 0) ? 1 : 0);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

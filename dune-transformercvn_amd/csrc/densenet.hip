@@ -111,7 +111,8 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
     const int mid = cfg.bn_size * cfg.growth;
     L.img = b.take((long)n * cfg.H * cfg.W * cfg.in_ch * esz);
     L.c0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
-    L.D.clear(); L.Y.clear(); L.bstatD.clear(); L.bstatY.clear();
+    L.D.clear(); L.Y.clear(); L.bstatD.clear(); L.bstatY.clear(); L.YA.clear();
+    L.zeros = b.take(1024);
     long max_part = (long)pool0_grid(n, blocks[0].H, blocks[0].W) * cfg.init_ch * 16;
     max_part = std::max(max_part, 512L * cfg.init_ch * 16);
     long maxY = 0;
@@ -121,6 +122,10 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
         std::vector<long> ys, bs;
         for (int l = 0; l < bg.L; ++l) { ys.push_back(b.take(M * mid * esz)); bs.push_back(b.take(mid * 16)); }
         L.Y.push_back(ys); L.bstatY.push_back(bs);
+        std::vector<long> yas;
+        if (cfg.mode == MODE_BF16)
+            for (int l = 0; l < bg.L; ++l) yas.push_back(b.take(M * mid * esz));
+        L.YA.push_back(yas);
         L.bstatD.push_back(b.take((long)bg.ld * 16));
         max_part = std::max(max_part, 512L * std::max(mid, bg.Ctot) * 16);   // every conv launcher uses <= 512 workgroups
         maxY = std::max(maxY, M * mid);
@@ -170,7 +175,7 @@ long DenseNetPlan::tab_off(const BnSlots& s) const {
 
 long DenseNetPlan::wk_bytes() const {
     long t = 0;
-    for (const auto& w : wk_list()) t += round_up((long)w.rows * w.Kp * esz, 256);
+    for (const auto& w : wk_list()) t += round_up(round_up(w.rows, 32) * w.Kp * esz, 256);
     return t;
 }
 
@@ -179,15 +184,16 @@ std::vector<WkEntry> DenseNetPlan::wk_list() const {
     std::vector<WkEntry> v;
     const int mid = cfg.bn_size * cfg.growth, g = cfg.growth;
     long off = 0;
-    auto add = [&](int slot, int N, int Cin, int taps, int transpose) {
+    auto add = [&](int slot, int N, int Cin, int taps, int transpose, int frag = 0) {
         WkEntry e;
-        e.slot = slot; e.N = N; e.Cin = Cin; e.taps = taps; e.transpose = transpose;
+        e.slot = slot; e.N = N; e.Cin = Cin; e.taps = taps; e.transpose = transpose; e.frag = frag;
         e.rows = transpose ? Cin : N;
         e.Kp = (int)round_up((long)taps * (transpose ? N : Cin), 32);
         e.off = off;
-        off += round_up((long)e.rows * e.Kp * esz, 256);
+        off += round_up(round_up(e.rows, 32) * e.Kp * esz, 256);
         v.push_back(e);
     };
+    const bool frag = cfg.mode == MODE_BF16;      // bf16 fast paths read weights in MFMA fragment order
     add(s_w0, cfg.init_ch, cfg.in_ch, 49, 0);
     for (const auto& bg : blocks) {
         for (const auto& ls : bg.layers) {
@@ -195,15 +201,22 @@ std::vector<WkEntry> DenseNetPlan::wk_list() const {
             add(ls.w2, g, mid, 9, 0);
             add(ls.w1, mid, ls.cin, 1, 1);     // dgrad layouts
             add(ls.w2, g, mid, 9, 1);
+            if (frag) { add(ls.w2, g, mid, 9, 0, 1); add(ls.w2, g, mid, 9, 1, 1); }
         }
         if (bg.has_trans) { add(bg.tw, bg.Ctot / 2, bg.Ctot, 1, 0); add(bg.tw, bg.Ctot / 2, bg.Ctot, 1, 1); }
     }
     return v;
 }
 
-const WkEntry& DenseNetPlan::wk_find(int slot, int transpose) const {
+const void* DenseNetPlan::wk_frag(const char* ws, const Layout& L, int slot, int transpose) const {
     for (const auto& e : wk_cache)
-        if (e.slot == slot && e.transpose == transpose) return e;
+        if (e.slot == slot && e.transpose == transpose && e.frag == 1) return ws + L.wk + e.off;
+    return nullptr;
+}
+
+const WkEntry& DenseNetPlan::wk_find(int slot, int transpose, int frag) const {
+    for (const auto& e : wk_cache)
+        if (e.slot == slot && e.transpose == transpose && e.frag == frag) return e;
     fprintf(stderr, "tcvn: wk_find miss\n");
     abort();
 }
@@ -239,7 +252,7 @@ int DenseNetPlan::upload_descs(char* ws, const Layout& L, hipStream_t st) {
     for (const auto& e : wk_cache) {
         PackDesc d;
         d.src = data[e.slot]; d.dst = ws + L.wk + e.off; d.N = e.N; d.Cin = e.Cin; d.taps = e.taps; d.Kp = e.Kp;
-        d.transpose = e.transpose;
+        d.transpose = e.transpose; d.frag = e.frag;
         pd.push_back(d);
     }
     std::vector<BnEvalDesc> bd;
@@ -304,6 +317,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
 
     // ---- pixel scatter + stem ----
     TCVN_CHECK(hipMemsetAsync(ws + L.img, 0, (size_t)n * cfg.H * cfg.W * cfg.in_ch * esz, st));
+    TCVN_CHECK(hipMemsetAsync(ws + L.zeros, 0, 1024, st));
     {
         ScatterArgs a{mode, coords, values, nnz, n, ws + L.img, cfg.H, cfg.W, cfg.in_ch, log_pixels, train ? noise_std : 0.f, seed};
         if ((rc = scatter_pixels(a, st))) return rc;
@@ -356,6 +370,12 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 a.mode = mode; a.amode = A_3X3; a.A = ws + L.Y[bi][l]; a.lda = mid; a.M = (int)M; a.N = g; a.K = 9 * mid;
                 a.Kp = e.Kp; a.C = mid; a.H = bg.H; a.W = bg.W; a.sc = t.sc; a.sh = t.sh; a.sl = data[ls.a2];
                 a.Wk = ws + L.wk + e.off; a.bias = data[ls.b2]; a.Out = D; a.ldo = bg.ld; a.n_off = ls.cin;
+                a.Wfrag = wk_frag(ws, L, ls.w2, 0);
+                if (mode == MODE_BF16) {       // materialise prelu(bn(Y)) once; the tile kernel stages it by LDS-DMA
+                    ActArgs act{ws + L.Y[bi][l], mid, M, mid, t.sc, t.sh, data[ls.a2], ws + L.YA[bi][l], mid};
+                    if ((rc = act_bf16(act, st))) return rc;
+                    a.Aact = ws + L.YA[bi][l]; a.zeros = ws + L.zeros;
+                }
                 a.part = train ? part : nullptr;
                 a.drop_p = train ? cfg.dropout : 0.f; a.seed = seed; a.stream_id = (uint32_t)(bi * 64 + l + 1);
                 a.nblk = conv_fwd_nblk(a);

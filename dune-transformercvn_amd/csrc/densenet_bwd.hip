@@ -33,7 +33,7 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     for (const auto& bg : blocks) L.pqD.push_back(b.take((long)bg.ld * 8));
     long gw = 0;
     for (const auto& e : wk_list())
-        if (!e.transpose) gw += round_up((long)e.N * e.Kp * 4, 256);
+        if (!e.transpose && !e.frag) gw += round_up((long)e.N * e.Kp * 4, 256);
     L.gwk = b.take(gw);
     L.zero_end = b.off;
     L.du = b.take(maxY * esz);
@@ -68,11 +68,11 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
     {
         long o = 0;
         for (size_t i = 0; i < wk_cache.size(); ++i)
-            if (!wk_cache[i].transpose) { gw_off[i] = o; o += round_up((long)wk_cache[i].N * wk_cache[i].Kp * 4, 256); }
+            if (!wk_cache[i].transpose && !wk_cache[i].frag) { gw_off[i] = o; o += round_up((long)wk_cache[i].N * wk_cache[i].Kp * 4, 256); }
     }
     auto gw_of = [&](int slot) -> float* {
         for (size_t i = 0; i < wk_cache.size(); ++i)
-            if (wk_cache[i].slot == slot && !wk_cache[i].transpose) return reinterpret_cast<float*>(ws + L.gwk + gw_off[i]);
+            if (wk_cache[i].slot == slot && !wk_cache[i].transpose && !wk_cache[i].frag) return reinterpret_cast<float*>(ws + L.gwk + gw_off[i]);
         return nullptr;
     };
     // device table of unpack descriptors (depends on ws)
@@ -80,7 +80,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
         std::vector<UnpackDesc> ud;
         for (size_t i = 0; i < wk_cache.size(); ++i) {
             const WkEntry& e = wk_cache[i];
-            if (e.transpose) continue;
+            if (e.transpose || e.frag) continue;
             UnpackDesc d{reinterpret_cast<const float*>(ws + L.gwk + gw_off[i]), grad[e.slot], e.N, e.Cin, e.taps, e.Kp};
             ud.push_back(d);
         }

@@ -17,12 +17,13 @@ struct BlockGeom {
     bool has_trans = false;
     BnSlots tn; int ta = -1, tw = -1, tb = -1;
 };
-struct WkEntry { int slot, N, Cin, taps, transpose, rows, Kp; long off; };
+struct WkEntry { int slot, N, Cin, taps, transpose, rows, Kp, frag; long off; };
 
 struct Layout {
     long img, c0, bstat0, part, tabs, F, Z, head_stat, wk, fwd_end, total;
     std::vector<long> D, bstatD;
-    std::vector<std::vector<long>> Y, bstatY;
+    std::vector<std::vector<long>> Y, bstatY, YA;     // YA: activated bf16 copies of Y (bf16 mode)
+    long zeros;
     // backward
     long du, du0, pq0, pqY, gwk, bpart, dF, dZ, zero_end;
     std::vector<long> G, pqD;
@@ -54,7 +55,8 @@ struct DenseNetPlan {
     long tab_off(const BnSlots& s) const;
     long wk_bytes() const;
     std::vector<WkEntry> wk_list() const;
-    const WkEntry& wk_find(int slot, int transpose) const;
+    const WkEntry& wk_find(int slot, int transpose, int frag = 0) const;
+    const void* wk_frag(const char* ws, const Layout& L, int slot, int transpose) const;   // null when absent
     int bind(void* const* d, void* const* g);
     int upload_descs(char* ws, const Layout& L, hipStream_t st);
     int forward(int n, const int32_t* coords, const float* values, long nnz, int log_pixels, float noise_std, float* out,

@@ -142,30 +142,55 @@ __global__ void k_head_pool(const HeadPoolArgs a) {
     }
 }
 
+// ---- materialised activation: Out = bf16(prelu(X*sc + sh, sl)), 8 channels (16 B) per thread ------------------------
+// Feeds the bf16 3x3 tile kernels, whose LDS images are then filled by LDS-DMA without touching the VALU.
+__global__ __launch_bounds__(256) void k_act_bf16(const ActArgs a) {
+    const bf16* X = reinterpret_cast<const bf16*>(a.X);
+    bf16* O = reinterpret_cast<bf16*>(a.Out);
+    const int cpr = a.C >> 3;                                  // chunks per row
+    const long total = (long)a.M * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / cpr;
+        const int c = (int)(i - m * cpr) * 8;
+        const u16x8 v = *reinterpret_cast<const u16x8*>(X + m * a.ldx + c);
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j]));
+        *reinterpret_cast<u16x8*>(O + m * a.ldo + c) = o;
+    }
+}
+
 // ---- weight re-layout -----------------------------------------------------------------------------------------------
-// transpose == 0 : dst[n][tap*Cin + c] = src[n][c][tap]                       (forward / wgrad operand layout)
-// transpose == 1 : dst[c][tap*N + n]   = src[n][c][tap]   (dgrad operand: rows = input channel, k = (tap, out ch))
+// transpose == 0 : logical B[n][tap*Cin + c] = src[n][c][tap]                   (forward / wgrad operand layout)
+// transpose == 1 : logical B[c][tap*N + n]   = src[n][c][tap]   (dgrad operand: rows = input channel, k = (tap, out ch))
+// frag == 0 : dst = B row-major [rows][Kp]
+// frag == 1 : dst in MFMA 32x32x16 B-fragment order: ((row/32 * Kp/16 + k/16) * 64 + ((k>>3)&1)*32 + row%32) * 8 + k%8, rows
+//             zero padded to a multiple of 32 -- one wave-instruction then reads 1 KiB contiguous
 template <typename T>
 __global__ void k_pack(const PackDesc* descs) {
     const PackDesc d = descs[blockIdx.y];
     T* dst = reinterpret_cast<T*>(d.dst);
     const int rows = d.transpose ? d.Cin : d.N;
-    const long total = (long)rows * d.Kp;
+    const int prow = d.frag ? (rows + 31) / 32 * 32 : rows;
+    const long total = (long)prow * d.Kp;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int r = (int)(i / d.Kp), k = (int)(i % d.Kp);
         float v = 0.f;
-        if (!d.transpose) {
-            if (k < d.taps * d.Cin) {
-                const int tap = k / d.Cin, c = k % d.Cin;
-                v = d.src[((long)r * d.Cin + c) * d.taps + tap];
-            }
-        } else {
-            if (k < d.taps * d.N) {
-                const int tap = k / d.N, n = k % d.N;
-                v = d.src[((long)n * d.Cin + r) * d.taps + tap];
+        if (r < rows) {
+            if (!d.transpose) {
+                if (k < d.taps * d.Cin) {
+                    const int tap = k / d.Cin, c = k % d.Cin;
+                    v = d.src[((long)r * d.Cin + c) * d.taps + tap];
+                }
+            } else {
+                if (k < d.taps * d.N) {
+                    const int tap = k / d.N, n = k % d.N;
+                    v = d.src[((long)n * d.Cin + r) * d.taps + tap];
+                }
             }
         }
-        dst[i] = from_f<T>(v);
+        const long o = d.frag ? ((((long)(r >> 5) * (d.Kp >> 4) + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (r & 31)) * 8 + (k & 7)) : i;
+        dst[o] = from_f<T>(v);
     }
 }
 
@@ -211,6 +236,15 @@ int pool0_fwd(const Pool0Args& a, hipStream_t st) {
 int head_pool_fwd(const HeadPoolArgs& a, hipStream_t st) {
     if (a.mode == MODE_F32) hipLaunchKernelGGL(k_head_pool<float>, dim3(a.n_img), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_head_pool<bf16>, dim3(a.n_img), dim3(256), 0, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int act_bf16(const ActArgs& a, hipStream_t st) {
+    if ((a.C & 7) || (a.ldx & 7) || (a.ldo & 7)) return -2;
+    const long total = (long)a.M * (a.C >> 3);
+    const long g = (total + 255) / 256;
+    hipLaunchKernelGGL(k_act_bf16, dim3((unsigned)(g < 4096 ? g : 4096)), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

@@ -17,10 +17,9 @@ typedef unsigned short bf16;   // storage type for bf16 activations / weights
 enum { MODE_F32 = 0, MODE_BF16 = 1 };
 
 __device__ __forceinline__ float bf2f(bf16 v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16 f2bf(float f) {          // round-to-nearest-even, NaN preserved
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16)((u >> 16) | 0x40);
-    return (bf16)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+__device__ __forceinline__ bf16 f2bf(float f) {          // round-to-nearest-even (v_cvt_pk_bf16_f32), NaN stays NaN
+    const __bf16 b = static_cast<__bf16>(f);
+    return __builtin_bit_cast(unsigned short, b);
 }
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
@@ -75,20 +74,27 @@ __device__ __forceinline__ float drop_scale(float p, uint64_t seed, uint32_t str
     return rng_uniform(seed, stream, idx) >= p ? 1.f / (1.f - p) : 0.f;
 }
 
-// Dropout mask of a [pixels, N] activation slice: one Philox call yields the four 32-bit words of the group
-// (pixel >> 2, channel n); pixel & 3 selects the word -- kernels that own 4 consecutive pixels of one channel share a call.
-__device__ __forceinline__ uint4 drop_words(uint64_t seed, uint32_t stream, long m, int n, int N) {
-    const uint64_t grp = (uint64_t)(m >> 2) * (uint64_t)N + (uint64_t)n;
-    return philox4((uint32_t)grp, (uint32_t)(grp >> 32), stream, 0x64726f70u, (uint32_t)seed, (uint32_t)(seed >> 32));
+// Dropout mask of a [pixels, N] activation slice.  Counter-based and stateless (recomputed in backward): one 32-bit
+// avalanche hash (lowbias32) per (pixel pair, channel) yields two 16-bit uniform draws; pixel & 1 selects the draw, so
+// kernels that own consecutive pixels of one channel share a hash.  keep <=> draw >= round(p * 65536).
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
 }
-__device__ __forceinline__ float drop_pick(const uint4& w, long m, float p) {
-    const int k = (int)(m & 3);
-    const uint32_t x = k == 0 ? w.x : k == 1 ? w.y : k == 2 ? w.z : w.w;
-    return (x >> 8) * (1.0f / 16777216.0f) >= p ? 1.f / (1.f - p) : 0.f;
+__device__ __forceinline__ uint32_t drop_key(uint64_t seed, uint32_t stream) {
+    return lowbias32((uint32_t)seed ^ lowbias32((uint32_t)(seed >> 32) + stream * 0x9E3779B9u));
+}
+__device__ __forceinline__ uint32_t drop_bits(uint32_t key, long m, int n, int N) {
+    const uint64_t grp = (uint64_t)(m >> 1) * (uint64_t)N + (uint64_t)n;
+    return lowbias32(((uint32_t)grp * 0x9E3779B1u) ^ key ^ ((uint32_t)(grp >> 32) * 0x85ebca77u));
+}
+__device__ __forceinline__ float drop_pick(uint32_t bits, long m, float p) {
+    const uint32_t draw = (m & 1) ? (bits >> 16) : (bits & 0xffffu);
+    return draw >= (uint32_t)(p * 65536.0f + 0.5f) ? 1.f / (1.f - p) : 0.f;
 }
 __device__ __forceinline__ float drop_scale_mn(float p, uint64_t seed, uint32_t stream, long m, int n, int N) {
     if (p <= 0.f) return 1.f;
-    return drop_pick(drop_words(seed, stream, m, n, N), m, p);
+    return drop_pick(drop_bits(drop_key(seed, stream), m, n, N), m, p);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

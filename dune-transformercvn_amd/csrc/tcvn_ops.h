@@ -23,6 +23,10 @@ struct ConvFwdArgs {
     const float *sc, *sh, *sl;
     const void* Wk; const float* bias;
     void* Out; long ldo; int n_off;
+    const void* Wfrag;               // optional: the same weights in MFMA fragment order (bf16 fast paths)
+    const void* Aact;                // optional: bf16 copy of A with the BN+PReLU already applied (k_act_bf16)
+    int dbg;                         // timing-ablation bits (TCVN_DBG env, validation builds only): 1 no DMA, 2 no MFMA, 4 no epilogue
+    const void* zeros;               // >= 256 B of zeros in device memory (source of padding rows for LDS-DMA)
     double* part; int nblk;          // [nblk][N][2]; nblk = grid.x
     float drop_p; uint64_t seed; uint32_t stream_id;
 };
@@ -77,8 +81,12 @@ int pool0_grid(int n_img, int Ho, int Wo);
 struct HeadPoolArgs { int mode; const void* X; long ldx; int n_img, HW, C; const float *sc, *sh, *sl; float* F; };
 int head_pool_fwd(const HeadPoolArgs& a, hipStream_t st);
 
+// Out[m][0:C] = bf16(prelu(X[m][0:C]*sc + sh, sl)) (bf16 in/out)
+struct ActArgs { const void* X; long ldx; long M; int C; const float *sc, *sh, *sl; void* Out; long ldo; };
+int act_bf16(const ActArgs& a, hipStream_t st);
+
 // Weight re-layout: reference OIHW fp32 -> kernel layout [N][Kp] (k = tap*Cin + c), typed T, zero padded.
-struct PackDesc { const float* src; void* dst; int N, Cin, taps, Kp; int transpose; };
+struct PackDesc { const float* src; void* dst; int N, Cin, taps, Kp; int transpose; int frag; };
 int pack_weights(const PackDesc* d_descs, int n, int mode, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------------------
