@@ -165,6 +165,160 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_bf16(const ConvFwdArgs g
 
 size_t fwd_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return 2 * r4 * 256 + 3 * r4 * 4 + 4 * 32 * 16; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient: dW[tap][c][n] = sum over padded positions p of Yact[p + shift(tap)][c] * eff[p][n].
+// The contraction runs over pixels, i.e. over the ROW index of both row-major LDS images, so both MFMA operands are
+// read transposed with ds_read_b64_tr_b16 (semantics checked by tools/micro/tr_read_test.hip): per 16-position k-step a
+// wave reads the eff fragment once and nine shifted Yact fragments, and owns the 9 x (32 c x 32 n) accumulators of its
+// 32-channel slice for the whole launch (144 accumulator registers); one atomic pass at the end.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8_t tr_frag(const char* smem_base, int off_lo, int off_hi) {
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem_base + off_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem_base + off_hi));
+    struct { s16x4 a, b; } pr = {lo, hi};
+    return __builtin_bit_cast(bf16x8_t, pr);
+}
+
+__global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradArgs g, int n_img, int ntiles, int swz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvFwdArgs& fa = g.fa;
+    const EffSrc& e = g.e;
+    const PadGeom q(n_img, fa.H, fa.W);
+    const int nrows4 = (q.rows() + 3) & ~3;
+    const int img_bytes = nrows4 * 256;
+    const int eff_off = 2 * img_bytes;                                    // two [TP][32] bf16 images, 64-B rows, unswizzled
+    int* tbl = reinterpret_cast<int*>(smem + eff_off + 2 * TP * 64);      // [3][nrows4]
+    float* bred = reinterpret_cast<float*>(smem + eff_off);        // [64][32], aliases the eff images after the last barrier
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
+    const bf16* __restrict__ YA = reinterpret_cast<const bf16*>(fa.Aact);
+    const char* __restrict__ zeros = reinterpret_cast<const char*>(fa.zeros);
+    const bf16* __restrict__ G = reinterpret_cast<const bf16*>(e.G);
+    const bf16* __restrict__ D = reinterpret_cast<const bf16*>(e.X);
+    const int nb = gridDim.x;
+    const int lb = swz ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const bool drop = e.drop_p > 0.f;
+    const uint32_t dkey = drop_key(e.seed, e.stream_id);
+
+    // eff staging: thread -> (rows ra = tid>>2 and ra+64, channel chunk ec = tid&3)
+    const int ec = tid & 3, ra = tid >> 2;
+    float cP[8], cQ[8], bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = ec * 8 + j;
+        cP[j] = n < e.N ? e.P[n] : 0.f; cQ[j] = n < e.N ? e.Q[n] : 0.f; bsum[j] = 0.f;
+    }
+    auto eff_load = [&](const int* rowpix, int i, u16x8& gv, u16x8& xv) -> int {
+        const int m = rowpix[q.halo + ra + 64 * i];
+        const long o = (long)(m >= 0 ? m : 0);
+        gv = *reinterpret_cast<const u16x8*>(G + o * e.ldg + e.c_off + ec * 8);
+        xv = *reinterpret_cast<const u16x8*>(D + o * e.ldx + e.c_off + ec * 8);
+        return m;
+    };
+    auto eff_store = [&](int buf, int i, int m, const u16x8& gv, const u16x8& xv) {
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = 0.f;
+            const int n = ec * 8 + j;
+            if (m >= 0 && n < e.N) {
+                t = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
+                if (drop) t *= drop_pick(drop_bits(dkey, m, n, e.N), m, e.drop_p);
+            }
+            o[j] = f2bf(t);
+            bsum[j] += bf2f(o[j]);
+        }
+        *reinterpret_cast<u16x8*>(smem + eff_off + buf * TP * 64 + (ra + 64 * i) * 64 + ec * 16) = o;
+    };
+    auto fill_tbl = [&](int slot, int tile) {
+        for (int rr = tid; rr < nrows4; rr += 256) tbl[slot * nrows4 + rr] = pix_of(q, tile * TP - q.halo + rr, invWp, invHp);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    if (lb < ntiles) fill_tbl(0, lb);
+    if (lb + nb < ntiles) fill_tbl(1, lb + nb);
+    __syncthreads();
+    if (lb < ntiles) {
+        dma_image(smem, 0, YA, zeros, tbl, nrows4, wave, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { u16x8 gv, xv; const int m = eff_load(tbl, i, gv, xv); eff_store(0, i, m, gv, xv); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // tr-read lane roles: group gq = lane>>4 -> (k half = gq>>1, column half = gq&1); lane 4q+p supplies row q, cols 4p..4p+3
+    const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int khalf = gq >> 1, chalf = gq & 1;
+    const int a_chunk = wave * 4 + 2 * chalf + (tp >> 1), a_sub = (tp & 1) * 8;       // Yact: this wave's 32 channels
+    const int b_colbyte = (16 * chalf + 4 * tp) * 2;                                  // eff: 32 channels
+
+    int cur = 0, ts = 0;
+    for (int t = lb; t < ntiles; t += nb, cur ^= 1, ts = ts == 2 ? 0 : ts + 1) {
+        const int tn = ts == 2 ? 0 : ts + 1, tnn = tn == 2 ? 0 : tn + 1;
+        const bool more = t + nb < ntiles;
+        u16x8 gv[2], xv[2];
+        int mm[2] = {-1, -1};
+        if (more) {
+            dma_image(smem, (cur ^ 1) * img_bytes, YA, zeros, tbl + tn * nrows4, nrows4, wave, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mm[i] = eff_load(tbl + tn * nrows4, i, gv[i], xv[i]);
+        }
+        const int image = cur * img_bytes, effb = eff_off + cur * TP * 64;
+#pragma unroll 2
+        for (int ks = 0; ks < TP / 16; ++ks) {
+            const int brow = ks * 16 + 8 * khalf + tq;
+            const bf16x8_t b = tr_frag(smem, effb + brow * 64 + b_colbyte, effb + (brow + 4) * 64 + b_colbyte);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int arow = q.halo + (tap / 3 - 1) * q.Wp + (tap % 3 - 1) + brow;
+                const int r2 = arow + 4;
+                const bf16x8_t a = tr_frag(smem, image + arow * 256 + ((a_chunk ^ (arow & 15)) << 4) + a_sub,
+                                           image + r2 * 256 + ((a_chunk ^ (r2 & 15)) << 4) + a_sub);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) eff_store(cur ^ 1, i, mm[i], gv[i], xv[i]);
+        }
+        if (t + 2 * nb < ntiles) fill_tbl(tnn, t + 2 * nb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // dW[tap*128 + c][n] += acc ; rows of the C tile are this wave's channels, columns the 32 output channels
+    const int n = lane & 31, hh = lane >> 5;
+    if (n < e.N) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                atomicAdd(g.dWk + ((long)tap * 128 + c) * 32 + n, acc[tap][i]);
+            }
+    }
+    if (g.dbias != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bred[ra * 32 + ec * 8 + j] = bsum[j];
+        __syncthreads();
+        if (tid < e.N) {
+            float sum = 0.f;
+            for (int rr = 0; rr < 64; ++rr) sum += bred[rr * 32 + tid];
+            atomicAdd(g.dbias + tid, sum);
+        }
+    }
+}
+
+size_t wgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return 2 * r4 * 256 + 2 * TP * 64 + 3 * r4 * 4; }
+
 int tile_grid(long ntiles) {            // one persistent workgroup per CU
     if (ntiles >= 256) return 256;
     if (ntiles >= 8) return (int)(ntiles / 8 * 8);
@@ -178,6 +332,8 @@ static bool tile_disabled() {
     static const bool off = getenv("TCVN_DISABLE_TILE") != nullptr;      // validation switch: force the generic kernels
     return off;
 }
+
+bool conv3x3_tile_enabled() { return !tile_disabled(); }
 
 bool conv3x3_tile_ok(const ConvFwdArgs& a) {
     if (tile_disabled()) return false;
@@ -209,6 +365,38 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
     static const int dbg = getenv("TCVN_DBG") ? atoi(getenv("TCVN_DBG")) : 0;
     b.dbg = dbg;
     hipLaunchKernelGGL(k_conv3x3_fwd_bf16, dim3(nb), dim3(256), smem, st, b, n_img, ntiles, (nb >= 8 && nb % 8 == 0) ? 1 : 0);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace tcvn
+
+namespace tcvn {
+using namespace t3;
+
+bool conv3x3_wgrad_tile_ok(const ConvWgradArgs& a) {
+    const ConvFwdArgs& fa = a.fa;
+    if (!conv3x3_tile_enabled() || a.mode != MODE_BF16 || fa.amode != A_3X3 || fa.C != 128 || a.e.N > 32) return false;
+    if (fa.Aact == nullptr || fa.zeros == nullptr || (a.e.ldg & 7) || (a.e.ldx & 7) || (a.e.c_off & 1)) return false;
+    if (fa.M % (fa.H * fa.W) != 0) return false;
+    const PadGeom q(fa.M / (fa.H * fa.W), fa.H, fa.W);
+    return q.gtot < (1L << 24) && wgrad_smem(q) <= 160 * 1024;
+}
+
+int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st) {
+    const int n_img = a.fa.M / (a.fa.H * a.fa.W);
+    const PadGeom q(n_img, a.fa.H, a.fa.W);
+    const int ntiles = (int)q.tiles();
+    const int nb = tile_grid(ntiles);
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wgrad_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024));
+        attr = true;
+    }
+    ProfScope ps("k_conv3x3_wgrad_bf16", 2.0 * a.fa.M * (double)a.e.N * a.fa.K, 0.0, st);
+    hipLaunchKernelGGL(k_conv3x3_wgrad_bf16, dim3(nb), dim3(256), wgrad_smem(q), st, a, n_img, ntiles,
+                       (nb >= 8 && nb % 8 == 0) ? 1 : 0);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

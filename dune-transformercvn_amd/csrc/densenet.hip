@@ -231,6 +231,7 @@ int DenseNetPlan::bind(void* const* d, void* const* g) {
         }
     }
     wk_cache = wk_list();
+    fast3x3 = cfg.mode == MODE_BF16 && cfg.bn_size * cfg.growth == 128 && cfg.growth <= 32 && conv3x3_tile_enabled();
     bound = true;
     desc_ws = nullptr;   // device descriptor tables are rebuilt on the next forward
     undesc_ws = nullptr;

@@ -81,7 +81,8 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
         for (size_t i = 0; i < wk_cache.size(); ++i) {
             const WkEntry& e = wk_cache[i];
             if (e.transpose || e.frag) continue;
-            UnpackDesc d{reinterpret_cast<const float*>(ws + L.gwk + gw_off[i]), grad[e.slot], e.N, e.Cin, e.taps, e.Kp};
+            UnpackDesc d{reinterpret_cast<const float*>(ws + L.gwk + gw_off[i]), grad[e.slot], e.N, e.Cin, e.taps, e.Kp,
+                         (fast3x3 && e.taps == 9) ? 1 : 0};
             ud.push_back(d);
         }
         n_unpack = (int)ud.size();
@@ -172,6 +173,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 w.fa.mode = mode; w.fa.amode = A_3X3; w.fa.A = Y; w.fa.lda = mid; w.fa.M = (int)M; w.fa.N = g; w.fa.K = 9 * mid;
                 w.fa.Kp = ef.Kp; w.fa.C = mid; w.fa.H = bg.H; w.fa.W = bg.W;
                 w.fa.sc = sc_of(ls.n2); w.fa.sh = sh_of(ls.n2); w.fa.sl = data[ls.a2];
+                if (fast3x3) { w.nfast = 1; w.fa.Aact = ws + L.YA[bi][l]; w.fa.zeros = ws + L.zeros; }
                 if ((rc = conv_wgrad(w, st))) return rc;
             }
             {   // conv2 data gradient -> DU (= sc2 * dU2) + norm2 partials

@@ -39,6 +39,7 @@ struct DenseNetPlan {
     BnSlots n0, nf, nl;
     std::vector<WkEntry> wk_cache;
     bool bound = false;
+    bool fast3x3 = false;            // bf16 padded-tile 3x3 kernels in use (decided at bind time)
     // device descriptor table (pack + eval BN descriptors)
     char* d_desc = nullptr; size_t desc_cap = 0; std::vector<char> h_desc;
     char* desc_ws = nullptr; long desc_total = 0; int n_pack = 0, n_bneval = 0;

@@ -132,7 +132,7 @@ __global__ void k_unpack(const UnpackDesc* descs) {
         const int tap = (int)(i % d.taps);
         const int c = (int)((i / d.taps) % d.Cin);
         const int n = (int)(i / ((long)d.taps * d.Cin));
-        d.dst[i] += d.src[(long)n * d.Kp + tap * d.Cin + c];
+        d.dst[i] += d.nfast ? d.src[((long)tap * d.Cin + c) * 32 + n] : d.src[(long)n * d.Kp + tap * d.Cin + c];
     }
 }
 

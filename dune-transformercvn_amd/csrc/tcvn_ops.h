@@ -37,6 +37,7 @@ int conv_fwd_nblk(const ConvFwdArgs& a);   // grid.x (== rows of `part`) conv_fw
 bool conv3x3_tile_ok(const ConvFwdArgs& a);
 int conv3x3_tile_nblk(const ConvFwdArgs& a);
 int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st);
+bool conv3x3_tile_enabled();                         // false when TCVN_DISABLE_TILE is set
 
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm plumbing
@@ -126,8 +127,11 @@ struct ConvWgradArgs {
     ConvFwdArgs fa;
     EffSrc e;
     float* dWk; float* dbias;
+    int nfast;        // 1: dWk is laid out [k][32] (out-channel fastest) and the padded-tile kernel must be used (bf16 3x3)
 };
 int conv_wgrad(const ConvWgradArgs& a, hipStream_t st);
+bool conv3x3_wgrad_tile_ok(const ConvWgradArgs& a);
+int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st);
 
 // Reduce the backward partials of one BatchNorm, emit parameter gradients and the (P, Q) coefficients of its input.
 struct BnBwdLinkArgs {
@@ -156,7 +160,7 @@ int pool0_bwd(const Pool0BwdArgs& a, hipStream_t st);
 int pool0_bwd_grid(int n_img, int Hin, int Win);
 
 // kernel-layout fp32 weight gradients -> reference OIHW gradients (accumulate)
-struct UnpackDesc { const float* src; float* dst; int N, Cin, taps, Kp; };
+struct UnpackDesc { const float* src; float* dst; int N, Cin, taps, Kp; int nfast; };   // nfast: src is [k][32]
 int unpack_wgrads(const UnpackDesc* d_descs, int n, hipStream_t st);
 
 }  // namespace tcvn
