@@ -317,6 +317,133 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Data gradient: dA[p][c] = sum_tap sum_n eff[p - shift(tap)][n] * W2[n][c][tap]  (128 channels out, K = 9 x 32), followed
+// by the PReLU + BatchNorm backward of norm2 on the bottleneck tensor Y.  The 32-channel eff image (gradient of the layer's
+// concat slice, dropout mask and BN mean-terms applied) is built once per tile in LDS; each wave owns 32 of the 128 output
+// channels for all 128 positions, so its 18 weight fragments stay in registers.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad_bf16(const ConvDgradArgs g, int n_img, int ntiles, int swz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const EffSrc& e = g.e;
+    const PadGeom q(n_img, g.H, g.W);
+    const int nrows4 = (q.rows() + 3) & ~3;
+    int* tbl = reinterpret_cast<int*>(smem + nrows4 * 64);                 // [nrows4] pixel index per image row
+    double* red = reinterpret_cast<double*>(smem);                          // [128][3] aliases the image after the last tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
+    const bf16* __restrict__ G = reinterpret_cast<const bf16*>(e.G);
+    const bf16* __restrict__ D = reinterpret_cast<const bf16*>(e.X);
+    const bf16* __restrict__ Y = reinterpret_cast<const bf16*>(g.Xin);
+    bf16* __restrict__ DU = reinterpret_cast<bf16*>(g.Gout);
+    const int nb = gridDim.x;
+    const int lb = swz ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const bool drop = e.drop_p > 0.f;
+    const uint32_t dkey = drop_key(e.seed, e.stream_id);
+
+    // weights of this wave's 32 output channels: fragment (row tile = wave, k-step) at ((wave*18 + ks)*64 + lane)*8
+    const bf16* __restrict__ Wf = reinterpret_cast<const bf16*>(g.Wfrag) + ((long)wave * 18 * 64 + lane) * 8;
+    bf16x8_t bw[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + i * 512);
+    const int c = wave * 32 + r;                                           // this lane's output channel
+    const float sc = g.sc[c], sh = g.sh[c], sl = g.sl[c];
+
+    const int ec = tid & 3, er0 = tid >> 2;                                // eff staging: chunk ec of rows er0, er0+64, ...
+    float cP[8], cQ[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = ec * 8 + j;
+        cP[j] = n < e.N ? e.P[n] : 0.f; cQ[j] = n < e.N ? e.Q[n] : 0.f;
+    }
+    double s1 = 0, s2 = 0, s3 = 0;
+    for (int t = lb; t < ntiles; t += nb) {
+        const int g0 = t * TP;
+        __syncthreads();
+        for (int rr = tid; rr < nrows4; rr += 256) tbl[rr] = pix_of(q, g0 - q.halo + rr, invWp, invHp);
+        __syncthreads();
+        // eff image: 16-B chunk ec of row rr at rr*64 + ((ec ^ ((rr>>2)&3)) << 4)
+        for (int rr = er0; rr < nrows4; rr += 64) {
+            const int m = tbl[rr];
+            u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (m >= 0) {
+                const u16x8 gv = *reinterpret_cast<const u16x8*>(G + (long)m * e.ldg + e.c_off + ec * 8);
+                const u16x8 xv = *reinterpret_cast<const u16x8*>(D + (long)m * e.ldx + e.c_off + ec * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = ec * 8 + j;
+                    float v = 0.f;
+                    if (n < e.N) {
+                        v = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
+                        if (drop) v *= drop_pick(drop_bits(dkey, m, n, e.N), m, e.drop_p);
+                    }
+                    o[j] = f2bf(v);
+                }
+            }
+            *reinterpret_cast<u16x8*>(smem + off64(rr, ec)) = o;
+        }
+        __syncthreads();
+
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int base = q.halo - ((tap / 3 - 1) * q.Wp + (tap % 3 - 1)) + r;      // source position = p - shift(tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int lr = base + mt * 32;
+                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(smem + off64(lr, 2 * ks + h));
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[tap * 2 + ks], acc[mt], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: u = sc*y + sh ; dU = dA * prelu'(u) ; DU = sc*dU.  Sums: fp32 over 4 consecutive rows, fp64 beyond
+        // (the BatchNorm backward subtracts nearly equal sums, so the partials must be better than fp32)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                float f1 = 0.f, f2 = 0.f, f3 = 0.f;
+#pragma unroll
+                for (int kr = 0; kr < 4; ++kr) {
+                    const int k = kq * 4 + kr;
+                    const int m = tbl[q.halo + mt * 32 + kr + 8 * kq + 4 * h];
+                    if (m >= 0) {
+                        const float y = bf2f(Y[(long)m * g.ldxin + c]);
+                        const float u = fmaf(y, sc, sh);
+                        const float dA = acc[mt][k];
+                        const float du = u > 0.f ? dA : sl * dA;
+                        f1 += du; f2 += du * y; f3 += u > 0.f ? 0.f : dA * u;
+                        DU[(long)m * g.ldgo + c] = f2bf(sc * du);
+                    }
+                }
+                s1 += (double)f1; s2 += (double)f2; s3 += (double)f3;
+            }
+    }
+    __syncthreads();
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
+    if (lane < 32) { red[c * 3] = s1; red[c * 3 + 1] = s2; red[c * 3 + 2] = s3; }
+    __syncthreads();
+    if (tid < 128) {
+        double* p = g.part + ((long)blockIdx.x * g.N + tid) * 3;
+        p[0] = red[tid * 3]; p[1] = red[tid * 3 + 1]; p[2] = red[tid * 3 + 2];
+    }
+}
+
+size_t dgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return r4 * 64 + r4 * 4 + 64; }
+int tile_grid2(long ntiles) {           // two workgroups per CU
+    if (ntiles >= 512) return 512;
+    if (ntiles >= 8) return (int)(ntiles / 8 * 8);
+    return (int)ntiles;
+}
+
 size_t wgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return 2 * r4 * 256 + 2 * TP * 64 + 3 * r4 * 4; }
 
 int tile_grid(long ntiles) {            // one persistent workgroup per CU
@@ -396,6 +523,34 @@ int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st) {
     }
     ProfScope ps("k_conv3x3_wgrad_bf16", 2.0 * a.fa.M * (double)a.e.N * a.fa.K, 0.0, st);
     hipLaunchKernelGGL(k_conv3x3_wgrad_bf16, dim3(nb), dim3(256), wgrad_smem(q), st, a, n_img, ntiles,
+                       (nb >= 8 && nb % 8 == 0) ? 1 : 0);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace tcvn
+
+namespace tcvn {
+using namespace t3;
+
+bool conv3x3_dgrad_tile_ok(const ConvDgradArgs& a) {
+    if (!conv3x3_tile_enabled() || a.mode != MODE_BF16 || a.dmode != DG_3X3 || a.N != 128 || a.e.N > 32 || a.Kp != 288) return false;
+    if (a.Wfrag == nullptr || a.accumulate || a.ldxin != 128 || a.ldgo != 128) return false;
+    if ((a.e.ldg & 7) || (a.e.ldx & 7) || (a.e.c_off & 1) || a.M % (a.H * a.W) != 0) return false;
+    const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
+    return q.gtot < (1L << 24) && q.rows() * 64 >= 128 * 24;
+}
+int conv3x3_dgrad_tile_nblk(const ConvDgradArgs& a) {
+    const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
+    return tile_grid2(q.tiles());
+}
+int conv3x3_dgrad_tile(const ConvDgradArgs& a, hipStream_t st) {
+    const int n_img = a.M / (a.H * a.W);
+    const PadGeom q(n_img, a.H, a.W);
+    const int ntiles = (int)q.tiles();
+    const int nb = tile_grid2(ntiles);
+    ProfScope ps("k_conv3x3_dgrad_bf16", 2.0 * a.M * (double)a.N * 9 * a.e.N, 0.0, st);
+    hipLaunchKernelGGL(k_conv3x3_dgrad_bf16, dim3(nb), dim3(256), dgrad_smem(q), st, a, n_img, ntiles,
                        (nb >= 8 && nb % 8 == 0) ? 1 : 0);
     TCVN_LAUNCH_CHECK();
     return 0;

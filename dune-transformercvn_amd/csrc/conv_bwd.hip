@@ -376,10 +376,13 @@ int wgrad_mode(const ConvWgradArgs& a, hipStream_t st) {
 
 }  // namespace
 
+int conv_dgrad_nblk(const ConvDgradArgs& a) { return conv3x3_dgrad_tile_ok(a) ? conv3x3_dgrad_tile_nblk(a) : conv_fwd_grid(a.M); }
+
 int conv_dgrad(const ConvDgradArgs& a, hipStream_t st) {
     if (a.M <= 0) return 0;
     if (a.Kp % BK != 0) return -2;
-    if (a.nblk != conv_fwd_grid(a.M)) { fprintf(stderr, "tcvn: conv_dgrad nblk mismatch\n"); return -3; }
+    if (a.nblk != conv_dgrad_nblk(a)) { fprintf(stderr, "tcvn: conv_dgrad nblk mismatch\n"); return -3; }
+    if (conv3x3_dgrad_tile_ok(a)) return conv3x3_dgrad_tile(a, st);
     char nm[96];
     snprintf(nm, sizeof(nm), "k_conv_dgrad<%s,%d,%d>", a.mode == MODE_F32 ? "float" : "bf16", a.dmode, a.N <= 32 ? 32 : a.N <= 64 ? 64 : 128);
     ProfScope ps(nm, 2.0 * a.M * (double)a.N * ((a.dmode == DG_3X3 ? 9 : 1) * a.e.N), 0.0, st);

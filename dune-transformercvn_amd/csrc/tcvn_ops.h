@@ -118,8 +118,13 @@ struct ConvDgradArgs {
     const float *sc, *sh, *sl;
     void* Gout; long ldgo; int accumulate;
     double* part; int nblk;        // [nblk][N][3]
+    const void* Wfrag;             // optional: Wt in MFMA fragment order (bf16 padded-tile 3x3 kernel)
 };
 int conv_dgrad(const ConvDgradArgs& a, hipStream_t st);
+int conv_dgrad_nblk(const ConvDgradArgs& a);      // grid.x (rows of `part`) conv_dgrad will use (<= 512)
+bool conv3x3_dgrad_tile_ok(const ConvDgradArgs& a);
+int conv3x3_dgrad_tile_nblk(const ConvDgradArgs& a);
+int conv3x3_dgrad_tile(const ConvDgradArgs& a, hipStream_t st);
 
 // dWk[n][k] += sum_m eff(m, n) * a(m, k)   (a = the forward A operand, regenerated), dbias[n] += sum_m eff(m, n)
 struct ConvWgradArgs {
