@@ -111,7 +111,7 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
     const int mid = cfg.bn_size * cfg.growth;
     L.img = b.take((long)n * cfg.H * cfg.W * cfg.in_ch * esz);
     L.c0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
-    L.D.clear(); L.Y.clear(); L.bstatD.clear(); L.bstatY.clear(); L.YA.clear();
+    L.D.clear(); L.Y.clear(); L.bstatD.clear(); L.bstatY.clear(); L.YA.clear(); L.XA.clear(); L.XP.clear();
     L.zeros = b.take(1024);
     long max_part = (long)pool0_grid(n, blocks[0].H, blocks[0].W) * cfg.init_ch * 16;
     max_part = std::max(max_part, 512L * cfg.init_ch * 16);
@@ -126,6 +126,14 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
         if (cfg.mode == MODE_BF16)
             for (int l = 0; l < bg.L; ++l) yas.push_back(b.take(M * mid * esz));
         L.YA.push_back(yas);
+        std::vector<long> xas;
+        for (int l = 0; l < bg.L; ++l) {
+            const int cin = bg.C0 + l * cfg.growth;
+            xas.push_back((cfg.mode == MODE_BF16 && cin % 8 == 0) ? b.take(M * cin * esz) : -1);
+        }
+        L.XA.push_back(xas);
+        const bool tfast = cfg.mode == MODE_BF16 && bg.has_trans && bg.Ctot % 16 == 0;
+        L.XP.push_back(tfast ? b.take((long)n * (bg.H / 2) * (bg.W / 2) * bg.Ctot * esz) : -1);
         L.bstatD.push_back(b.take((long)bg.ld * 16));
         max_part = std::max(max_part, 512L * std::max(mid, bg.Ctot) * 16);   // every conv launcher uses <= 512 workgroups
         maxY = std::max(maxY, M * mid);
@@ -353,6 +361,11 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         for (int l = 0; l < bg.L; ++l) {
             const LayerSlots& ls = bg.layers[l];
             if ((rc = link(ls.n1, part, new_nblk, new_ld, new_c0, new_n, bstatD, M))) return rc;
+            if (train && L.XA[bi][l] >= 0) {     // activated copy of the 1x1 input: operand of the bf16 weight-gradient GEMM
+                Tab t1 = tab(ls.n1);
+                ActArgs act{D, bg.ld, M, ls.cin, t1.sc, t1.sh, data[ls.a1], ws + L.XA[bi][l], ls.cin};
+                if ((rc = act_bf16(act, st))) return rc;
+            }
             {   // bottleneck 1x1: D[:, 0:cin] -> Y
                 const WkEntry& e = wk_find(ls.w1, 0);
                 Tab t = tab(ls.n1);
@@ -390,6 +403,10 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             const WkEntry& e = wk_find(bg.tw, 0);
             Tab t = tab(bg.tn);
             const long Mn = (long)n * nb.H * nb.W;
+            if (train && L.XP[bi] >= 0) {
+                ActPoolArgs ap{D, bg.ld, n, bg.H, bg.W, bg.Ctot, t.sc, t.sh, data[bg.ta], ws + L.XP[bi], bg.Ctot};
+                if ((rc = act_pool_bf16(ap, st))) return rc;
+            }
             ConvFwdArgs a{};
             a.mode = mode; a.amode = A_1X1_POOL; a.A = D; a.lda = bg.ld; a.M = (int)Mn; a.N = bg.Ctot / 2; a.K = bg.Ctot;
             a.Kp = e.Kp; a.C = bg.Ctot; a.H = nb.H; a.W = nb.W; a.Hin = bg.H; a.Win = bg.W;

@@ -37,6 +37,7 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     L.gwk = b.take(gw);
     L.zero_end = b.off;
     L.du = b.take(maxY * esz);
+    L.ey = b.take(maxY * esz);
     L.pqY = b.take((long)mid * 8);
     L.du0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
     L.pq0 = b.take((long)cfg.init_ch * 8);
@@ -147,7 +148,13 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             w.fa.mode = mode; w.fa.amode = A_1X1_POOL; w.fa.A = D; w.fa.lda = bg.ld; w.fa.M = (int)Mn; w.fa.N = Nt;
             w.fa.K = bg.Ctot; w.fa.Kp = ef.Kp; w.fa.C = bg.Ctot; w.fa.H = nb.H; w.fa.W = nb.W; w.fa.Hin = bg.H; w.fa.Win = bg.W;
             w.fa.sc = sc_of(bg.tn); w.fa.sh = sh_of(bg.tn); w.fa.sl = data[bg.ta];
-            if ((rc = conv_wgrad(w, st))) return rc;
+            if (L.XP[bi] >= 0 && conv3x3_tile_enabled()) {
+                // materialise the output gradient once (+ bias gradient), then dW = ET^T x XP on the TN GEMM
+                EffMatArgs em{e, Mn, ws + L.ey, Nt, grad[bg.tb]};
+                if ((rc = eff_materialize_bf16(em, st))) return rc;
+                GemmTnArgs ga{ws + L.ey, Nt, Nt, ws + L.XP[bi], bg.Ctot, bg.Ctot, Mn, gw_of(bg.tw), ef.Kp, ws + L.zeros};
+                if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<transition>", st))) return rc;
+            } else if ((rc = conv_wgrad(w, st))) return rc;
             ConvDgradArgs d{};
             d.mode = mode; d.dmode = DG_1X1_POOL; d.e = e; d.M = (int)Mn; d.N = bg.Ctot; d.Kp = et.Kp;
             d.H = nb.H; d.W = nb.W; d.Hin = bg.H; d.Win = bg.W; d.Wt = ws + L.wk + et.off;
@@ -195,7 +202,12 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 w.fa.mode = mode; w.fa.amode = A_1X1; w.fa.A = D; w.fa.lda = bg.ld; w.fa.M = (int)M; w.fa.N = mid; w.fa.K = ls.cin;
                 w.fa.Kp = ef.Kp; w.fa.C = ls.cin; w.fa.H = bg.H; w.fa.W = bg.W;
                 w.fa.sc = sc_of(ls.n1); w.fa.sh = sh_of(ls.n1); w.fa.sl = data[ls.a1];
-                if ((rc = conv_wgrad(w, st))) return rc;
+                if (L.XA[bi][l] >= 0 && conv3x3_tile_enabled()) {
+                    EffMatArgs em{e1, M, ws + L.ey, mid, grad[ls.b1]};
+                    if ((rc = eff_materialize_bf16(em, st))) return rc;
+                    GemmTnArgs ga{ws + L.ey, mid, mid, ws + L.XA[bi][l], ls.cin, ls.cin, M, gw_of(ls.w1), ef.Kp, ws + L.zeros};
+                    if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<conv1>", st))) return rc;
+                } else if ((rc = conv_wgrad(w, st))) return rc;
             }
             {   // conv1 data gradient -> G[:, 0:cin] += sc1 * dU1, norm1 partials
                 const WkEntry& et = wk_find(ls.w1, 1);

@@ -160,6 +160,33 @@ __global__ __launch_bounds__(256) void k_act_bf16(const ActArgs a) {
     }
 }
 
+// ---- pooled activation in front of a transition conv: XP[img,ho,wo,c] = 1/4 sum_{2x2} prelu(bn(D)) ------------------------
+__global__ __launch_bounds__(256) void k_act_pool_bf16(const ActPoolArgs a) {
+    const bf16* X = reinterpret_cast<const bf16*>(a.X);
+    bf16* O = reinterpret_cast<bf16*>(a.Out);
+    const int Ho = a.Hin / 2, Wo = a.Win / 2, cpr = a.C >> 3;
+    const long total = (long)a.n_img * Ho * Wo * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long mo = i / cpr;
+        const int c = (int)(i - mo * cpr) * 8;
+        const int wo = (int)(mo % Wo);
+        const int ho = (int)((mo / Wo) % Ho);
+        const long img = mo / ((long)Wo * Ho);
+        const long p00 = (img * a.Hin + 2 * ho) * a.Win + 2 * wo;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u16x8 v = *reinterpret_cast<const u16x8*>(X + (p00 + (t >> 1) * a.Win + (t & 1)) * a.ldx + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j]);
+        }
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j] * 0.25f);
+        *reinterpret_cast<u16x8*>(O + mo * a.ldo + c) = o;
+    }
+}
+
 // ---- weight re-layout -----------------------------------------------------------------------------------------------
 // transpose == 0 : logical B[n][tap*Cin + c] = src[n][c][tap]                   (forward / wgrad operand layout)
 // transpose == 1 : logical B[c][tap*N + n]   = src[n][c][tap]   (dgrad operand: rows = input channel, k = (tap, out ch))
@@ -245,6 +272,15 @@ int act_bf16(const ActArgs& a, hipStream_t st) {
     const long total = (long)a.M * (a.C >> 3);
     const long g = (total + 255) / 256;
     hipLaunchKernelGGL(k_act_bf16, dim3((unsigned)(g < 4096 ? g : 4096)), dim3(256), 0, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int act_pool_bf16(const ActPoolArgs& a, hipStream_t st) {
+    if ((a.C & 7) || (a.ldx & 7) || (a.ldo & 7)) return -2;
+    const long total = (long)a.n_img * (a.Hin / 2) * (a.Win / 2) * (a.C >> 3);
+    const long g = (total + 255) / 256;
+    hipLaunchKernelGGL(k_act_pool_bf16, dim3((unsigned)(g < 4096 ? g : 4096)), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

@@ -125,6 +125,45 @@ __global__ __launch_bounds__(256) void k_pool0_bwd(const Pool0BwdArgs a) {
     }
 }
 
+// materialised effective gradient (see EffMatArgs); block = 64 chunk-lanes x 4 rows
+__global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a) {
+    __shared__ float red[4][64][8];
+    const EffSrc& e = a.e;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int cpr = e.N >> 3;
+    const bf16* G = reinterpret_cast<const bf16*>(e.G);
+    const bf16* X = reinterpret_cast<const bf16*>(e.X);
+    bf16* O = reinterpret_cast<bf16*>(a.Out);
+    float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tx < cpr) {
+        float cP[8], cQ[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cP[j] = e.P[tx * 8 + j]; cQ[j] = e.Q[tx * 8 + j]; }
+        const uint32_t dkey = drop_key(e.seed, e.stream_id);
+        for (long m = (long)blockIdx.x * 4 + ty; m < a.M; m += (long)gridDim.x * 4) {
+            const u16x8 gv = *reinterpret_cast<const u16x8*>(G + m * e.ldg + e.c_off + tx * 8);
+            const u16x8 xv = *reinterpret_cast<const u16x8*>(X + m * e.ldx + e.c_off + tx * 8);
+            u16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
+                if (e.drop_p > 0.f) t *= drop_pick(drop_bits(dkey, m, tx * 8 + j, e.N), m, e.drop_p);
+                o[j] = f2bf(t);
+                cs[j] += bf2f(o[j]);
+            }
+            *reinterpret_cast<u16x8*>(O + m * a.ldo + tx * 8) = o;
+        }
+    }
+    if (a.colsum == nullptr) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[ty][tx][j] = cs[j];
+    __syncthreads();
+    if (ty == 0 && tx < cpr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(a.colsum + tx * 8 + j, red[0][tx][j] + red[1][tx][j] + red[2][tx][j] + red[3][tx][j]);
+    }
+}
+
 __global__ void k_unpack(const UnpackDesc* descs) {
     const UnpackDesc d = descs[blockIdx.y];
     const long total = (long)d.N * d.Cin * d.taps;
@@ -163,6 +202,16 @@ int pool0_bwd(const Pool0BwdArgs& a, hipStream_t st) {
     if (a.nblk != pool0_bwd_grid(a.n_img, a.Hin, a.Win)) return -3;
     if (a.mode == MODE_F32) hipLaunchKernelGGL(k_pool0_bwd<float>, dim3(a.nblk), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_pool0_bwd<bf16>, dim3(a.nblk), dim3(256), 0, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int eff_materialize_bf16(const EffMatArgs& a, hipStream_t st) {
+    if (a.M <= 0) return 0;
+    const EffSrc& e = a.e;
+    if ((e.N & 7) || e.N > 512 || (e.ldg & 7) || (e.ldx & 7) || (e.c_off & 7) || (a.ldo & 7)) return -2;
+    const long g = (a.M + 3) / 4;
+    hipLaunchKernelGGL(k_eff_mat, dim3((unsigned)(g < 2048 ? g : 2048)), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

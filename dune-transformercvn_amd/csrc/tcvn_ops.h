@@ -164,6 +164,20 @@ struct Pool0BwdArgs {
 int pool0_bwd(const Pool0BwdArgs& a, hipStream_t st);
 int pool0_bwd_grid(int n_img, int Hin, int Win);
 
+// bf16 TN GEMM over pixels (gemm_tn.hip): C[i][j] += sum_m L[m][i] * R[m][j]
+struct GemmTnArgs { const void* L; long ldl; int Li; const void* R; long ldr; int Rj; long M; float* C; long ldc; const void* zeros; };
+bool gemm_tn_ok(const GemmTnArgs& a);
+int gemm_tn_bf16(const GemmTnArgs& a, const char* label, hipStream_t st);
+
+// Materialise an effective gradient: Out[m][n] = bf16(drop * (G[m][c_off+n] + P[n]*X[m][c_off+n] + Q[n])), n < e.N;
+// optionally colsum[n] += sum_m Out[m][n] (bias gradient of the producing convolution).
+struct EffMatArgs { EffSrc e; long M; void* Out; long ldo; float* colsum; };
+int eff_materialize_bf16(const EffMatArgs& a, hipStream_t st);
+
+// XP[m'][c] = bf16( 1/4 sum_{2x2} prelu(D[pixel][c]*sc + sh, sl) )  (pooled activation in front of a transition's 1x1 conv)
+struct ActPoolArgs { const void* X; long ldx; int n_img, Hin, Win, C; const float *sc, *sh, *sl; void* Out; long ldo; };
+int act_pool_bf16(const ActPoolArgs& a, hipStream_t st);
+
 // kernel-layout fp32 weight gradients -> reference OIHW gradients (accumulate)
 struct UnpackDesc { const float* src; float* dst; int N, Cin, taps, Kp; int nfast; };   // nfast: src is [k][32]
 int unpack_wgrads(const UnpackDesc* d_descs, int n, hipStream_t st);
