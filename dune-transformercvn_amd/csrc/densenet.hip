@@ -209,9 +209,15 @@ std::vector<WkEntry> DenseNetPlan::wk_list() const {
             add(ls.w2, g, mid, 9, 0);
             add(ls.w1, mid, ls.cin, 1, 1);     // dgrad layouts
             add(ls.w2, g, mid, 9, 1);
-            if (frag) { add(ls.w2, g, mid, 9, 0, 1); add(ls.w2, g, mid, 9, 1, 1); }
+            if (frag) {
+                add(ls.w2, g, mid, 9, 0, 1); add(ls.w2, g, mid, 9, 1, 1);
+                add(ls.w1, mid, ls.cin, 1, 0, 1); add(ls.w1, mid, ls.cin, 1, 1, 1);
+            }
         }
-        if (bg.has_trans) { add(bg.tw, bg.Ctot / 2, bg.Ctot, 1, 0); add(bg.tw, bg.Ctot / 2, bg.Ctot, 1, 1); }
+        if (bg.has_trans) {
+            add(bg.tw, bg.Ctot / 2, bg.Ctot, 1, 0); add(bg.tw, bg.Ctot / 2, bg.Ctot, 1, 1);
+            if (frag) { add(bg.tw, bg.Ctot / 2, bg.Ctot, 1, 0, 1); add(bg.tw, bg.Ctot / 2, bg.Ctot, 1, 1, 1); }
+        }
     }
     return v;
 }
@@ -361,12 +367,21 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         for (int l = 0; l < bg.L; ++l) {
             const LayerSlots& ls = bg.layers[l];
             if ((rc = link(ls.n1, part, new_nblk, new_ld, new_c0, new_n, bstatD, M))) return rc;
-            if (train && L.XA[bi][l] >= 0) {     // activated copy of the 1x1 input: operand of the bf16 weight-gradient GEMM
+            const bool fast1 = L.XA[bi][l] >= 0 && conv3x3_tile_enabled() && mid % 8 == 0 && ls.cin <= 512;
+            if (fast1) {     // activated copy of the 1x1 input: operand of the bf16 GEMMs (forward and weight gradient)
                 Tab t1 = tab(ls.n1);
                 ActArgs act{D, bg.ld, M, ls.cin, t1.sc, t1.sh, data[ls.a1], ws + L.XA[bi][l], ls.cin};
                 if ((rc = act_bf16(act, st))) return rc;
             }
-            {   // bottleneck 1x1: D[:, 0:cin] -> Y
+            if (fast1) {   // bottleneck 1x1 on the NT GEMM: XA x W1^T -> Y
+                const WkEntry& e = wk_find(ls.w1, 0, 1);
+                GemmNtArgs a{};
+                a.epi = EPI_FWD; a.A = ws + L.XA[bi][l]; a.lda = ls.cin; a.K = ls.cin; a.M = M; a.N = mid;
+                a.Wfrag = ws + L.wk + e.off; a.Kp = e.Kp; a.zeros = ws + L.zeros; a.bias = data[ls.b1];
+                a.Out = ws + L.Y[bi][l]; a.ldo = mid; a.n_off = 0; a.part = train ? part : nullptr; a.nblk = gemm_nt_nblk(a);
+                if ((rc = gemm_nt_bf16(a, "k_gemm_nt_bf16<fwd1x1>", st))) return rc;
+                if ((rc = link(ls.n2, part, a.nblk, mid, 0, mid, reinterpret_cast<double*>(ws + L.bstatY[bi][l]), M))) return rc;
+            } else {   // bottleneck 1x1: D[:, 0:cin] -> Y
                 const WkEntry& e = wk_find(ls.w1, 0);
                 Tab t = tab(ls.n1);
                 ConvFwdArgs a{};
@@ -403,9 +418,20 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             const WkEntry& e = wk_find(bg.tw, 0);
             Tab t = tab(bg.tn);
             const long Mn = (long)n * nb.H * nb.W;
-            if (train && L.XP[bi] >= 0) {
+            const bool fastt = L.XP[bi] >= 0 && conv3x3_tile_enabled() && bg.Ctot <= 512;
+            if (fastt) {
                 ActPoolArgs ap{D, bg.ld, n, bg.H, bg.W, bg.Ctot, t.sc, t.sh, data[bg.ta], ws + L.XP[bi], bg.Ctot};
                 if ((rc = act_pool_bf16(ap, st))) return rc;
+            }
+            if (fastt) {
+                const WkEntry& ef = wk_find(bg.tw, 0, 1);
+                GemmNtArgs ga{};
+                ga.epi = EPI_FWD; ga.A = ws + L.XP[bi]; ga.lda = bg.Ctot; ga.K = bg.Ctot; ga.M = Mn; ga.N = bg.Ctot / 2;
+                ga.Wfrag = ws + L.wk + ef.off; ga.Kp = ef.Kp; ga.zeros = ws + L.zeros; ga.bias = data[bg.tb];
+                ga.Out = ws + L.D[bi + 1]; ga.ldo = nb.ld; ga.n_off = 0; ga.part = train ? part : nullptr; ga.nblk = gemm_nt_nblk(ga);
+                if ((rc = gemm_nt_bf16(ga, "k_gemm_nt_bf16<fwdtrans>", st))) return rc;
+                init_nblk = ga.nblk; init_ld = bg.Ctot / 2;
+                continue;
             }
             ConvFwdArgs a{};
             a.mode = mode; a.amode = A_1X1_POOL; a.A = D; a.lda = bg.ld; a.M = (int)Mn; a.N = bg.Ctot / 2; a.K = bg.Ctot;

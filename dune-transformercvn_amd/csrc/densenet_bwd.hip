@@ -148,13 +148,25 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             w.fa.mode = mode; w.fa.amode = A_1X1_POOL; w.fa.A = D; w.fa.lda = bg.ld; w.fa.M = (int)Mn; w.fa.N = Nt;
             w.fa.K = bg.Ctot; w.fa.Kp = ef.Kp; w.fa.C = bg.Ctot; w.fa.H = nb.H; w.fa.W = nb.W; w.fa.Hin = bg.H; w.fa.Win = bg.W;
             w.fa.sc = sc_of(bg.tn); w.fa.sh = sh_of(bg.tn); w.fa.sl = data[bg.ta];
-            if (L.XP[bi] >= 0 && conv3x3_tile_enabled()) {
+            if (L.XP[bi] >= 0 && conv3x3_tile_enabled() && bg.Ctot <= 512) {
                 // materialise the output gradient once (+ bias gradient), then dW = ET^T x XP on the TN GEMM
                 EffMatArgs em{e, Mn, ws + L.ey, Nt, grad[bg.tb]};
                 if ((rc = eff_materialize_bf16(em, st))) return rc;
                 GemmTnArgs ga{ws + L.ey, Nt, Nt, ws + L.XP[bi], bg.Ctot, bg.Ctot, Mn, gw_of(bg.tw), ef.Kp, ws + L.zeros};
                 if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<transition>", st))) return rc;
             } else if ((rc = conv_wgrad(w, st))) return rc;
+            if (L.XP[bi] >= 0 && conv3x3_tile_enabled() && bg.Ctot <= 512) {
+                const WkEntry& etf = wk_find(bg.tw, 1, 1);
+                GemmNtArgs ga{};
+                ga.epi = EPI_DGRAD_POOL; ga.A = ws + L.ey; ga.lda = Nt; ga.K = Nt; ga.M = Mn; ga.N = bg.Ctot;
+                ga.Wfrag = ws + L.wk + etf.off; ga.Kp = etf.Kp; ga.zeros = ws + L.zeros;
+                ga.Xin = D; ga.ldxin = bg.ld; ga.sc = sc_of(bg.tn); ga.sh = sh_of(bg.tn); ga.sl = data[bg.ta];
+                ga.Gout = G; ga.ldgo = bg.ld; ga.H = nb.H; ga.W = nb.W; ga.Hin = bg.H; ga.Win = bg.W;
+                ga.part = part; ga.nblk = gemm_nt_nblk(ga);
+                if ((rc = gemm_nt_bf16(ga, "k_gemm_nt_bf16<dgradtrans>", st))) return rc;
+                if ((rc = bwd_link(bg.tn, ga.nblk, bstatD, M, P, Q, 1, bg.ta))) return rc;
+                goto layers;
+            }
             ConvDgradArgs d{};
             d.mode = mode; d.dmode = DG_1X1_POOL; d.e = e; d.M = (int)Mn; d.N = bg.Ctot; d.Kp = et.Kp;
             d.H = nb.H; d.W = nb.W; d.Hin = bg.H; d.Win = bg.W; d.Wt = ws + L.wk + et.off;
@@ -164,6 +176,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             if ((rc = bwd_link(bg.tn, d.nblk, bstatD, M, P, Q, 1, bg.ta))) return rc;
         }
 
+    layers:
         for (int l = bg.L - 1; l >= 0; --l) {
             const LayerSlots& ls = bg.layers[l];
             char* Y = ws + L.Y[bi][l];
@@ -202,14 +215,23 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 w.fa.mode = mode; w.fa.amode = A_1X1; w.fa.A = D; w.fa.lda = bg.ld; w.fa.M = (int)M; w.fa.N = mid; w.fa.K = ls.cin;
                 w.fa.Kp = ef.Kp; w.fa.C = ls.cin; w.fa.H = bg.H; w.fa.W = bg.W;
                 w.fa.sc = sc_of(ls.n1); w.fa.sh = sh_of(ls.n1); w.fa.sl = data[ls.a1];
-                if (L.XA[bi][l] >= 0 && conv3x3_tile_enabled()) {
+                if (L.XA[bi][l] >= 0 && conv3x3_tile_enabled() && ls.cin <= 512) {
                     EffMatArgs em{e1, M, ws + L.ey, mid, grad[ls.b1]};
                     if ((rc = eff_materialize_bf16(em, st))) return rc;
                     GemmTnArgs ga{ws + L.ey, mid, mid, ws + L.XA[bi][l], ls.cin, ls.cin, M, gw_of(ls.w1), ef.Kp, ws + L.zeros};
                     if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<conv1>", st))) return rc;
                 } else if ((rc = conv_wgrad(w, st))) return rc;
             }
-            {   // conv1 data gradient -> G[:, 0:cin] += sc1 * dU1, norm1 partials
+            if (L.XA[bi][l] >= 0 && conv3x3_tile_enabled() && ls.cin <= 512) {   // conv1 data gradient on the NT GEMM (A = EY)
+                const WkEntry& etf = wk_find(ls.w1, 1, 1);
+                GemmNtArgs ga{};
+                ga.epi = EPI_DGRAD; ga.A = ws + L.ey; ga.lda = mid; ga.K = mid; ga.M = M; ga.N = ls.cin;
+                ga.Wfrag = ws + L.wk + etf.off; ga.Kp = etf.Kp; ga.zeros = ws + L.zeros;
+                ga.Xin = D; ga.ldxin = bg.ld; ga.sc = sc_of(ls.n1); ga.sh = sh_of(ls.n1); ga.sl = data[ls.a1];
+                ga.Gout = G; ga.ldgo = bg.ld; ga.part = part; ga.nblk = gemm_nt_nblk(ga);
+                if ((rc = gemm_nt_bf16(ga, "k_gemm_nt_bf16<dgrad1x1>", st))) return rc;
+                if ((rc = bwd_link(ls.n1, ga.nblk, bstatD, M, P, Q, 1, ls.a1))) return rc;
+            } else {   // conv1 data gradient -> G[:, 0:cin] += sc1 * dU1, norm1 partials
                 const WkEntry& et = wk_find(ls.w1, 1);
                 ConvDgradArgs d{};
                 d.mode = mode; d.dmode = DG_1X1; d.e = e1; d.M = (int)M; d.N = ls.cin; d.Kp = et.Kp; d.H = bg.H; d.W = bg.W;

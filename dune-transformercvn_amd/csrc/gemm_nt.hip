@@ -1,0 +1,238 @@
+// bf16 "NT" GEMM for the 1x1 convolutions on materialised operands:
+//     C[m][n] = sum_k A[m][k] * W[n][k]        A = activated input / output gradient [M][K] (bf16, row-major, LDS-DMA'd)
+// with three fused epilogues (reference: Bottleneck.bottleneck_block.conv1 / Transition.conv, layers/dense_net.py:18-27,84-94):
+//   EPI_FWD        + bias -> bf16 -> Out[m][n_off+n], per-channel (sum, sum^2) partials for the next BatchNorm
+//   EPI_DGRAD      PReLU + BatchNorm backward against the norm's input x = Xin[m][n]: G[m][n] += sc*dU, 3 partial sums
+//   EPI_DGRAD_POOL same, the row being a 2x2-pooled pixel: each of its four source pixels receives dA/4
+// One persistent workgroup per CU walks 128-row tiles; each wave owns 32 of the tile's 128 output columns for all rows, so its
+// weight fragments (<= 32 k-steps) live in registers for the whole launch.  The fp32 C tile is exchanged through LDS so that the
+// epilogue touches HBM with 16 B per lane (x, G read / G write) instead of 2-byte accesses in MFMA layout.
+#include "tcvn_ops.h"
+#include "prof.h"
+
+namespace tcvn {
+
+namespace {
+
+constexpr int ROWS = 128, CLD = 132;            // C tile leading dimension (floats), padded
+constexpr int MAXKS = 32;                       // k-steps of 16 held in registers (K <= 512)
+
+__device__ __forceinline__ void dma_a(char* smem_base, int buf_off, const bf16* __restrict__ A, long lda, int K, int k0, long m0,
+                                      long M, const char* __restrict__ zeros, int wave, int lane) {
+    const int rsub = lane >> 4, slot = lane & 15;
+#pragma unroll
+    for (int i = 0; i < ROWS / 16; ++i) {
+        const int rg = wave + 4 * i;
+        const int r = rg * 4 + rsub;
+        const int col = k0 + ((slot ^ (r & 15)) << 3);
+        const long m = m0 + r;
+        const char* src = (m < M && col < K) ? reinterpret_cast<const char*>(A + m * lda + col) : zeros + (slot << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem_base + buf_off + rg * 1024), 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = ROWS * 256;
+    float* Cs = reinterpret_cast<float*>(smem + 2 * TILE);                 // [ROWS][CLD]
+    double* red = reinterpret_cast<double*>(smem + 2 * TILE);              // [4][128][3] aliases Cs after the last tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * 128;
+    const bf16* __restrict__ A = reinterpret_cast<const bf16*>(g.A);
+    const char* __restrict__ zeros = reinterpret_cast<const char*>(g.zeros);
+    const int ksteps = g.Kp >> 4, nkc = (g.K + 127) >> 7;
+    const long mtiles = (g.M + ROWS - 1) / ROWS;
+
+    // this wave's weight fragments: row tile (n0/32 + wave), all k-steps
+    const bf16* __restrict__ Wf = reinterpret_cast<const bf16*>(g.Wfrag) + (((long)(blockIdx.y * 4 + wave) * ksteps) * 64 + lane) * 8;
+    const bool wave_live = n0 + wave * 32 < g.N;
+    bf16x8_t bw[MAXKS];
+#pragma unroll
+    for (int i = 0; i < MAXKS; ++i)
+        if (i < ksteps && wave_live) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + (long)i * 512);
+        else
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bw[i][j] = (__bf16)0.f;
+
+    // epilogue role: 16 threads per row (8 channels each), rows c_r0 + 16*i
+    const int c8 = tid & 15, c_r0 = tid >> 4;
+    const int ncol = n0 + c8 * 8;                                         // first output column of this thread's chunk
+    const bool col_ok = ncol < g.N;                                        // N % 8 == 0
+    float cb[8], csc[8], csh[8], csl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        cb[j] = (EPI == EPI_FWD && col_ok) ? g.bias[ncol + j] : 0.f;
+        csc[j] = (EPI != EPI_FWD && col_ok) ? g.sc[ncol + j] : 0.f;
+        csh[j] = (EPI != EPI_FWD && col_ok) ? g.sh[ncol + j] : 0.f;
+        csl[j] = (EPI != EPI_FWD && col_ok) ? g.sl[ncol + j] : 0.f;
+    }
+    double st1[8], st2[8], st3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { st1[j] = 0; st2[j] = 0; st3[j] = 0; }
+
+    long mt = blockIdx.x;
+    if (mt < mtiles) dma_a(smem, 0, A, g.lda, g.K, 0, mt * ROWS, g.M, zeros, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (; mt < mtiles; mt += gridDim.x) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < MAXKS / 8; ++kc) {
+            if (kc < nkc) {
+                // prefetch the next A tile (next k-chunk of this row tile, or the first chunk of the next row tile)
+                if (kc + 1 < nkc) dma_a(smem, (cur ^ 1) * TILE, A, g.lda, g.K, (kc + 1) * 128, mt * ROWS, g.M, zeros, wave, lane);
+                else if (mt + gridDim.x < mtiles) dma_a(smem, (cur ^ 1) * TILE, A, g.lda, g.K, 0, (mt + gridDim.x) * ROWS, g.M, zeros, wave, lane);
+                const int ab = cur * TILE;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (kc * 8 + ks < ksteps) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = i * 32 + r;
+                            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(smem + ab + row * 256 + (((2 * ks + h) ^ (row & 15)) << 4));
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[kc * 8 + ks], acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+        // C tile -> LDS (fp32): row = i*32 + (e&3) + 8*(e>>2) + 4*h, column = wave*32 + r
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Cs[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wave * 32 + r] = acc[i][e];
+        __syncthreads();
+        if (col_ok) {
+            float f1[8], f2[8], f3[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { f1[j] = 0.f; f2[j] = 0.f; f3[j] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < ROWS / 16; ++i) {
+                const int rr = c_r0 + 16 * i;
+                const long m = mt * ROWS + rr;
+                if (m < g.M) {
+                    const float4 ca = *reinterpret_cast<const float4*>(Cs + rr * CLD + c8 * 8);
+                    const float4 cc = *reinterpret_cast<const float4*>(Cs + rr * CLD + c8 * 8 + 4);
+                    const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cc.x, cc.y, cc.z, cc.w};
+                    if (EPI == EPI_FWD) {
+                        u16x8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            o[j] = f2bf(cv[j] + cb[j]);
+                            const float x = bf2f(o[j]);
+                            f1[j] += x; f2[j] += x * x;
+                        }
+                        *reinterpret_cast<u16x8*>(reinterpret_cast<bf16*>(g.Out) + m * g.ldo + g.n_off + ncol) = o;
+                    } else {
+                        const int npx = EPI == EPI_DGRAD_POOL ? 4 : 1;
+                        long p00 = m;
+                        if (EPI == EPI_DGRAD_POOL) {
+                            const int hw = g.H * g.W;
+                            const long img = m / hw;
+                            const int rem = (int)(m - img * hw);
+                            const int ho = rem / g.W, wo = rem - ho * g.W;
+                            p00 = (img * g.Hin + 2 * ho) * g.Win + 2 * wo;
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if (t < npx) {
+                                const long px = EPI == EPI_DGRAD_POOL ? p00 + (t >> 1) * g.Win + (t & 1) : m;
+                                const u16x8 xv = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16*>(g.Xin) + px * g.ldxin + ncol);
+                                bf16* gp = reinterpret_cast<bf16*>(g.Gout) + px * g.ldgo + ncol;
+                                const u16x8 gv = *reinterpret_cast<const u16x8*>(gp);
+                                u16x8 o;
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) {
+                                    const float x = bf2f(xv[j]);
+                                    const float u = fmaf(x, csc[j], csh[j]);
+                                    const float dA = EPI == EPI_DGRAD_POOL ? 0.25f * cv[j] : cv[j];
+                                    const float du = u > 0.f ? dA : csl[j] * dA;
+                                    f1[j] += du; f2[j] += du * x; f3[j] += u > 0.f ? 0.f : dA * u;
+                                    o[j] = f2bf(bf2f(gv[j]) + csc[j] * du);
+                                }
+                                *reinterpret_cast<u16x8*>(gp) = o;
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { st1[j] += (double)f1[j]; st2[j] += (double)f2[j]; st3[j] += (double)f3[j]; }
+        }
+        __syncthreads();
+    }
+    if (g.part == nullptr) return;
+    // reduce over the 16 row groups: 4 per wave by shuffles (lanes differing in bits 4,5), then across waves through LDS
+    constexpr int NS = EPI == EPI_FWD ? 2 : 3;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        st1[j] += __shfl_xor(st1[j], 16); st1[j] += __shfl_xor(st1[j], 32);
+        st2[j] += __shfl_xor(st2[j], 16); st2[j] += __shfl_xor(st2[j], 32);
+        if (NS == 3) { st3[j] += __shfl_xor(st3[j], 16); st3[j] += __shfl_xor(st3[j], 32); }
+    }
+    __syncthreads();
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double* p = red + ((wave * 128) + c8 * 8 + j) * 3;
+            p[0] = st1[j]; p[1] = st2[j]; p[2] = st3[j];
+        }
+    }
+    __syncthreads();
+    if (tid < 128 && n0 + tid < g.N) {
+        double a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += red[(w * 128 + tid) * 3]; b += red[(w * 128 + tid) * 3 + 1]; c += red[(w * 128 + tid) * 3 + 2]; }
+        double* p = g.part + ((long)blockIdx.x * g.N + n0 + tid) * NS;
+        p[0] = a; p[1] = b;
+        if (NS == 3) p[2] = c;
+    }
+}
+
+}  // namespace
+
+bool gemm_nt_ok(const GemmNtArgs& a) {
+    if (!a.A || !a.Wfrag || !a.zeros || (a.lda & 7) || (a.K & 7) || (a.N & 7) || a.Kp > MAXKS * 16 || (a.Kp & 15)) return false;
+    if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.Wfrag) & 15)) return false;
+    if (a.epi == EPI_FWD) return (a.ldo & 7) == 0 && (a.n_off & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Out) & 15) == 0;
+    return (a.ldxin & 7) == 0 && (a.ldgo & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Xin) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.Gout) & 15) == 0;
+}
+int gemm_nt_nblk(const GemmNtArgs& a) {
+    const long mt = (a.M + ROWS - 1) / ROWS;
+    return (int)(mt < 256 ? mt : 256);
+}
+int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
+    if (a.M <= 0) return 0;
+    if (!gemm_nt_ok(a)) return -2;
+    if (a.part != nullptr && a.nblk != gemm_nt_nblk(a)) { fprintf(stderr, "tcvn: gemm_nt nblk mismatch\n"); return -3; }
+    const size_t smem = 2 * ROWS * 256 + (size_t)ROWS * CLD * 4;
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD_POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    ProfScope ps(label, 2.0 * a.M * (double)a.N * a.K, 0.0, st);
+    const dim3 grid(gemm_nt_nblk(a), cdiv(a.N, 128));
+    if (a.epi == EPI_FWD) hipLaunchKernelGGL(k_gemm_nt_bf16<EPI_FWD>, grid, dim3(256), smem, st, a);
+    else if (a.epi == EPI_DGRAD) hipLaunchKernelGGL(k_gemm_nt_bf16<EPI_DGRAD>, grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL(k_gemm_nt_bf16<EPI_DGRAD_POOL>, grid, dim3(256), smem, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace tcvn

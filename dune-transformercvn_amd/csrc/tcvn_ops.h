@@ -169,6 +169,24 @@ struct GemmTnArgs { const void* L; long ldl; int Li; const void* R; long ldr; in
 bool gemm_tn_ok(const GemmTnArgs& a);
 int gemm_tn_bf16(const GemmTnArgs& a, const char* label, hipStream_t st);
 
+// bf16 NT GEMM with fused 1x1-convolution epilogues (gemm_nt.hip)
+enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_DGRAD_POOL = 2 };
+struct GemmNtArgs {
+    int epi;
+    const void* A; long lda; int K;          // [M][lda] bf16, K columns used
+    long M; int N;                           // output columns (multiple of 8)
+    const void* Wfrag; int Kp;               // weights [N][Kp] in MFMA fragment order
+    const void* zeros;
+    const float* bias; void* Out; long ldo; int n_off;             // EPI_FWD
+    const void* Xin; long ldxin; const float *sc, *sh, *sl;        // EPI_DGRAD*: BatchNorm input + its table
+    void* Gout; long ldgo;
+    int H, W, Hin, Win;                      // EPI_DGRAD_POOL geometry (rows = pooled pixels H x W of inputs Hin x Win)
+    double* part; int nblk;                  // [nblk][N][2 (fwd) | 3 (dgrad)]
+};
+bool gemm_nt_ok(const GemmNtArgs& a);
+int gemm_nt_nblk(const GemmNtArgs& a);
+int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st);
+
 // Materialise an effective gradient: Out[m][n] = bf16(drop * (G[m][c_off+n] + P[n]*X[m][c_off+n] + Q[n])), n < e.N;
 // optionally colsum[n] += sum_m Out[m][n] (bias gradient of the producing convolution).
 struct EffMatArgs { EffSrc e; long M; void* Out; long ldo; float* colsum; };
