@@ -296,23 +296,23 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
 
     // dW[tap*128 + c][n] += acc ; rows of the C tile are this wave's channels, columns the 32 output channels
     const int n = lane & 31, hh = lane >> 5;
-    if (n < e.N) {
+    {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int c = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                atomicAdd(g.dWk + ((long)tap * 128 + c) * 32 + n, acc[tap][i]);
+                g.slab[(long)blockIdx.x * (9 * 128 * 32) + ((long)tap * 128 + c) * 32 + n] = acc[tap][i];
             }
     }
     if (g.dbias != nullptr) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) bred[ra * 32 + ec * 8 + j] = bsum[j];
         __syncthreads();
-        if (tid < e.N) {
+        if (tid < 32) {
             float sum = 0.f;
             for (int rr = 0; rr < 64; ++rr) sum += bred[rr * 32 + tid];
-            atomicAdd(g.dbias + tid, sum);
+            g.slab[(long)gridDim.x * (9 * 128 * 32) + blockIdx.x * 32 + tid] = tid < e.N ? sum : 0.f;
         }
     }
 }
@@ -521,11 +521,17 @@ int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st) {
                                        160 * 1024));
         attr = true;
     }
-    ProfScope ps("k_conv3x3_wgrad_bf16", 2.0 * a.fa.M * (double)a.e.N * a.fa.K, 0.0, st);
-    hipLaunchKernelGGL(k_conv3x3_wgrad_bf16, dim3(nb), dim3(256), wgrad_smem(q), st, a, n_img, ntiles,
-                       (nb >= 8 && nb % 8 == 0) ? 1 : 0);
-    TCVN_LAUNCH_CHECK();
-    return 0;
+    if (a.slab == nullptr || (long)nb * (9 * 128 * 32 + 32) * 4 > a.slab_bytes || a.dbias == nullptr) return -3;
+    {
+        ProfScope ps("k_conv3x3_wgrad_bf16", 2.0 * a.fa.M * (double)a.e.N * a.fa.K, 0.0, st);
+        hipLaunchKernelGGL(k_conv3x3_wgrad_bf16, dim3(nb), dim3(256), wgrad_smem(q), st, a, n_img, ntiles,
+                           (nb >= 8 && nb % 8 == 0) ? 1 : 0);
+        TCVN_LAUNCH_CHECK();
+    }
+    int rc = slab_reduce(a.slab, nb, 9 * 128 * 32, a.dWk, st);
+    if (rc) return rc;
+    // bias partials [nb][32] -> dbias[0:N)  (the 32-wide rows are zero beyond N)
+    return slab_reduce(a.slab + (long)nb * (9 * 128 * 32), nb, a.e.N, a.dbias, st, 32);
 }
 
 }  // namespace tcvn

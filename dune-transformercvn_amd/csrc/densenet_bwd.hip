@@ -12,6 +12,7 @@ using namespace tcvn;
 
 namespace {
 constexpr float kEps = 1e-5f;
+constexpr long kSlabBytes = 48L << 20;      // per-workgroup partial weight gradients (<= 256 x 147 KB) and column sums
 struct Bump {
     long off;
     long take(long bytes) { long o = off; off += round_up(bytes, 256); return o; }
@@ -38,6 +39,7 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     L.zero_end = b.off;
     L.du = b.take(maxY * esz);
     L.ey = b.take(maxY * esz);
+    L.slab = b.take(kSlabBytes);
     L.pqY = b.take((long)mid * 8);
     L.du0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
     L.pq0 = b.take((long)cfg.init_ch * 8);
@@ -150,9 +152,10 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             w.fa.sc = sc_of(bg.tn); w.fa.sh = sh_of(bg.tn); w.fa.sl = data[bg.ta];
             if (L.XP[bi] >= 0 && conv3x3_tile_enabled() && bg.Ctot <= 512) {
                 // materialise the output gradient once (+ bias gradient), then dW = ET^T x XP on the TN GEMM
-                EffMatArgs em{e, Mn, ws + L.ey, Nt, grad[bg.tb]};
+                EffMatArgs em{e, Mn, ws + L.ey, Nt, grad[bg.tb], reinterpret_cast<float*>(ws + L.slab)};
                 if ((rc = eff_materialize_bf16(em, st))) return rc;
-                GemmTnArgs ga{ws + L.ey, Nt, Nt, ws + L.XP[bi], bg.Ctot, bg.Ctot, Mn, gw_of(bg.tw), ef.Kp, ws + L.zeros};
+                GemmTnArgs ga{ws + L.ey, Nt, Nt, ws + L.XP[bi], bg.Ctot, bg.Ctot, Mn, gw_of(bg.tw), ef.Kp, ws + L.zeros,
+                              reinterpret_cast<float*>(ws + L.slab), kSlabBytes};
                 if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<transition>", st))) return rc;
             } else if ((rc = conv_wgrad(w, st))) return rc;
             if (L.XP[bi] >= 0 && conv3x3_tile_enabled() && bg.Ctot <= 512) {
@@ -193,7 +196,10 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 w.fa.mode = mode; w.fa.amode = A_3X3; w.fa.A = Y; w.fa.lda = mid; w.fa.M = (int)M; w.fa.N = g; w.fa.K = 9 * mid;
                 w.fa.Kp = ef.Kp; w.fa.C = mid; w.fa.H = bg.H; w.fa.W = bg.W;
                 w.fa.sc = sc_of(ls.n2); w.fa.sh = sh_of(ls.n2); w.fa.sl = data[ls.a2];
-                if (fast3x3) { w.nfast = 1; w.fa.Aact = ws + L.YA[bi][l]; w.fa.zeros = ws + L.zeros; }
+                if (fast3x3) {
+                    w.nfast = 1; w.fa.Aact = ws + L.YA[bi][l]; w.fa.zeros = ws + L.zeros;
+                    w.slab = reinterpret_cast<float*>(ws + L.slab); w.slab_bytes = kSlabBytes;
+                }
                 if ((rc = conv_wgrad(w, st))) return rc;
             }
             {   // conv2 data gradient -> DU (= sc2 * dU2) + norm2 partials
@@ -216,9 +222,10 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 w.fa.Kp = ef.Kp; w.fa.C = ls.cin; w.fa.H = bg.H; w.fa.W = bg.W;
                 w.fa.sc = sc_of(ls.n1); w.fa.sh = sh_of(ls.n1); w.fa.sl = data[ls.a1];
                 if (L.XA[bi][l] >= 0 && conv3x3_tile_enabled() && ls.cin <= 512) {
-                    EffMatArgs em{e1, M, ws + L.ey, mid, grad[ls.b1]};
+                    EffMatArgs em{e1, M, ws + L.ey, mid, grad[ls.b1], reinterpret_cast<float*>(ws + L.slab)};
                     if ((rc = eff_materialize_bf16(em, st))) return rc;
-                    GemmTnArgs ga{ws + L.ey, mid, mid, ws + L.XA[bi][l], ls.cin, ls.cin, M, gw_of(ls.w1), ef.Kp, ws + L.zeros};
+                    GemmTnArgs ga{ws + L.ey, mid, mid, ws + L.XA[bi][l], ls.cin, ls.cin, M, gw_of(ls.w1), ef.Kp, ws + L.zeros,
+                                  reinterpret_cast<float*>(ws + L.slab), kSlabBytes};
                     if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<conv1>", st))) return rc;
                 } else if ((rc = conv_wgrad(w, st))) return rc;
             }

@@ -23,7 +23,7 @@ struct Layout {
     long img, c0, bstat0, part, tabs, F, Z, head_stat, wk, fwd_end, total;
     std::vector<long> D, bstatD;
     std::vector<std::vector<long>> Y, bstatY, YA;     // YA: activated bf16 copies of Y (bf16 mode)
-    long zeros, ey;
+    long zeros, ey, slab;
     std::vector<std::vector<long>> XA;   // activated bf16 copies of the 1x1-conv inputs (per layer, -1 if absent)
     std::vector<long> XP;                // pooled activated transition inputs (-1 if absent)
     // backward

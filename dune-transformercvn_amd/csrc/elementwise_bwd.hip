@@ -125,11 +125,12 @@ __global__ __launch_bounds__(256) void k_pool0_bwd(const Pool0BwdArgs a) {
     }
 }
 
-// materialised effective gradient (see EffMatArgs); block = 64 chunk-lanes x 4 rows
-__global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a) {
-    __shared__ float red[4][64][8];
+// materialised effective gradient (see EffMatArgs); block = W chunk-lanes (W = pow2 >= N/8) x 256/W rows, 16 B per thread
+__global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a, int wlog) {
+    __shared__ float red[256][8];
     const EffSrc& e = a.e;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int W = 1 << wlog, rpb = 256 >> wlog;
+    const int tx = threadIdx.x & (W - 1), ty = threadIdx.x >> wlog;
     const int cpr = e.N >> 3;
     const bf16* G = reinterpret_cast<const bf16*>(e.G);
     const bf16* X = reinterpret_cast<const bf16*>(e.X);
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { cP[j] = e.P[tx * 8 + j]; cQ[j] = e.Q[tx * 8 + j]; }
         const uint32_t dkey = drop_key(e.seed, e.stream_id);
-        for (long m = (long)blockIdx.x * 4 + ty; m < a.M; m += (long)gridDim.x * 4) {
+        for (long m = (long)blockIdx.x * rpb + ty; m < a.M; m += (long)gridDim.x * rpb) {
             const u16x8 gv = *reinterpret_cast<const u16x8*>(G + m * e.ldg + e.c_off + tx * 8);
             const u16x8 xv = *reinterpret_cast<const u16x8*>(X + m * e.ldx + e.c_off + tx * 8);
             u16x8 o;
@@ -156,11 +157,39 @@ __global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a) {
     }
     if (a.colsum == nullptr) return;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[ty][tx][j] = cs[j];
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = cs[j];
     __syncthreads();
     if (ty == 0 && tx < cpr) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(a.colsum + tx * 8 + j, red[0][tx][j] + red[1][tx][j] + red[2][tx][j] + red[3][tx][j]);
+        for (int j = 0; j < 8; ++j) {
+            float sum = 0.f;
+            for (int q = 0; q < rpb; ++q) sum += red[q * W + tx][j];
+            a.slab[(long)blockIdx.x * e.N + tx * 8 + j] = sum;       // reduced by k_slab_reduce (same-line atomics serialise)
+        }
+    }
+}
+
+// dst[i] += sum_s slab[s*stride + i]: block = 64 columns x 4 slab lanes; grid.y splits the slabs (<= 16 atomics per element)
+__global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slab, int nslab, long count, float* dst, long stride,
+                                                     int per_y) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + cx;
+    const int s0 = blockIdx.y * per_y, s1 = min(nslab, s0 + per_y);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < count) {
+        int k = s0 + sg;
+        for (; k + 12 < s1; k += 16) {
+            a0 += slab[(long)k * stride + i]; a1 += slab[(long)(k + 4) * stride + i];
+            a2 += slab[(long)(k + 8) * stride + i]; a3 += slab[(long)(k + 12) * stride + i];
+        }
+        for (; k < s1; k += 4) a0 += slab[(long)k * stride + i];
+    }
+    red[sg][cx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sg == 0 && i < count) {
+        const float v = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+        if (gridDim.y == 1) dst[i] += v; else atomicAdd(dst + i, v);
     }
 }
 
@@ -210,8 +239,24 @@ int eff_materialize_bf16(const EffMatArgs& a, hipStream_t st) {
     if (a.M <= 0) return 0;
     const EffSrc& e = a.e;
     if ((e.N & 7) || e.N > 512 || (e.ldg & 7) || (e.ldx & 7) || (e.c_off & 7) || (a.ldo & 7)) return -2;
-    const long g = (a.M + 3) / 4;
-    hipLaunchKernelGGL(k_eff_mat, dim3((unsigned)(g < 2048 ? g : 2048)), dim3(256), 0, st, a);
+    int wlog = 0;
+    while ((1 << wlog) < (e.N >> 3)) ++wlog;
+    const int rpb = 256 >> wlog;
+    const long g = (a.M + rpb - 1) / rpb;
+    const int nb = (int)(g < 1024 ? g : 1024);
+    if (a.colsum != nullptr && a.slab == nullptr) return -3;
+    hipLaunchKernelGGL(k_eff_mat, dim3(nb), dim3(256), 0, st, a, wlog);
+    TCVN_LAUNCH_CHECK();
+    if (a.colsum != nullptr) return slab_reduce(a.slab, nb, e.N, a.colsum, st);
+    return 0;
+}
+
+int slab_reduce(const float* slab, int nslab, long count, float* dst, hipStream_t st, long stride) {
+    if (count <= 0 || nslab <= 0) return 0;
+    int ny = cdiv(nslab, 64);
+    if (ny > 16) ny = 16;
+    const int per_y = cdiv(nslab, ny);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(count, 64), ny), dim3(256), 0, st, slab, nslab, count, dst, stride > 0 ? stride : count, per_y);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

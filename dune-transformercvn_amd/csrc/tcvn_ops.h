@@ -132,6 +132,7 @@ struct ConvWgradArgs {
     ConvFwdArgs fa;
     EffSrc e;
     float* dWk; float* dbias;
+    float* slab; long slab_bytes;   // scratch for per-workgroup partial gradients (padded-tile kernel)
     int nfast;        // 1: dWk is laid out [k][32] (out-channel fastest) and the padded-tile kernel must be used (bf16 3x3)
 };
 int conv_wgrad(const ConvWgradArgs& a, hipStream_t st);
@@ -165,7 +166,10 @@ int pool0_bwd(const Pool0BwdArgs& a, hipStream_t st);
 int pool0_bwd_grid(int n_img, int Hin, int Win);
 
 // bf16 TN GEMM over pixels (gemm_tn.hip): C[i][j] += sum_m L[m][i] * R[m][j]
-struct GemmTnArgs { const void* L; long ldl; int Li; const void* R; long ldr; int Rj; long M; float* C; long ldc; const void* zeros; };
+struct GemmTnArgs { const void* L; long ldl; int Li; const void* R; long ldr; int Rj; long M; float* C; long ldc; const void* zeros;
+                    float* slab; long slab_bytes; };     // slab: scratch for per-slice partial tiles (no contended atomics)
+// dst[i] += sum_s slab[s*count + i]   (deterministic reduction of per-workgroup partial results)
+int slab_reduce(const float* slab, int nslab, long count, float* dst, hipStream_t st, long stride = 0);   // stride 0 = count
 bool gemm_tn_ok(const GemmTnArgs& a);
 int gemm_tn_bf16(const GemmTnArgs& a, const char* label, hipStream_t st);
 
@@ -189,7 +193,7 @@ int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st);
 
 // Materialise an effective gradient: Out[m][n] = bf16(drop * (G[m][c_off+n] + P[n]*X[m][c_off+n] + Q[n])), n < e.N;
 // optionally colsum[n] += sum_m Out[m][n] (bias gradient of the producing convolution).
-struct EffMatArgs { EffSrc e; long M; void* Out; long ldo; float* colsum; };
+struct EffMatArgs { EffSrc e; long M; void* Out; long ldo; float* colsum; float* slab; };   // slab: >= 2048*N floats when colsum
 int eff_materialize_bf16(const EffMatArgs& a, hipStream_t st);
 
 // XP[m'][c] = bf16( 1/4 sum_{2x2} prelu(D[pixel][c]*sc + sh, sl) )  (pooled activation in front of a transition's 1x1 conv)
