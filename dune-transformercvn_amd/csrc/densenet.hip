@@ -459,7 +459,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
     r.save_mean = hs; r.save_rstd = hs + cfg.out_dim; r.train = train; r.eps = kEps; r.momentum = kMom;
     r.drop_p = train ? cfg.dropout : 0.f; r.seed = seed; r.stream_id = 0x4000u;
     if ((rc = rows_bn_fwd(r, st))) return rc;
-    last_seed = seed; last_n = n;
+    last_seed = seed; last_n = n; last_coords = coords; last_nnz = nnz;
     return 0;
 }
 

@@ -24,7 +24,7 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     const int mid = cfg.bn_size * cfg.growth;
     L.G.clear(); L.pqD.clear();
     // --- zeroed at the start of every backward: G, pqD, gwk (contiguous) ---
-    long bpart = (long)pool0_bwd_grid(n, Hc, Wc) * cfg.init_ch * 24;
+    long bpart = (long)std::max(pool0_bwd_grid(n, Hc, Wc), pool0_bwd_vec_grid(n, Hc, Wc)) * cfg.init_ch * 24;
     bpart = std::max(bpart, (long)head_pool_bwd_grid(n) * Cf * 24);
     for (const auto& bg : blocks) {
         const long M = (long)n * bg.H * bg.W;
@@ -261,7 +261,10 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
         EffSrc e{ws + L.G[0], b0.ld, ws + L.D[0], b0.ld, 0, cfg.init_ch, P, Q, 0.f, 0, 0};
         Pool0BwdArgs a{mode, ws + L.c0, n, Hc, Wc, cfg.init_ch, sc_of(n0), sh_of(n0), data[s_a0], e, b0.H, b0.W, ws + L.du0, part,
                        pool0_bwd_grid(n, Hc, Wc)};
-        if ((rc = pool0_bwd(a, st))) return rc;
+        const bool vec = pool0_bwd_vec_ok(a) && conv3x3_tile_enabled();
+        if (vec) { a.nblk = pool0_bwd_vec_grid(n, Hc, Wc); rc = pool0_bwd_vec(a, st); }
+        else rc = pool0_bwd(a, st);
+        if (rc) return rc;
         if ((rc = bwd_link(n0, a.nblk, reinterpret_cast<const double*>(ws + L.bstat0), M0, P0, Q0, 0, s_a0))) return rc;
         EffSrc e0{ws + L.du0, cfg.init_ch, ws + L.c0, cfg.init_ch, 0, cfg.init_ch, P0, Q0, 0.f, 0, 0};
         const WkEntry& ef = wk_find(s_w0, 0);
@@ -269,7 +272,12 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
         w.mode = mode; w.e = e0; w.dWk = gw_of(s_w0); w.dbias = grad[s_b0];
         w.fa.mode = mode; w.fa.amode = A_STEM; w.fa.A = ws + L.img; w.fa.lda = cfg.in_ch; w.fa.M = (int)M0; w.fa.N = cfg.init_ch;
         w.fa.K = 49 * cfg.in_ch; w.fa.Kp = ef.Kp; w.fa.C = cfg.in_ch; w.fa.H = Hc; w.fa.W = Wc; w.fa.Hin = cfg.H; w.fa.Win = cfg.W;
-        if ((rc = conv_wgrad(w, st))) return rc;
+        if (mode == MODE_BF16 && conv3x3_tile_enabled() && cfg.in_ch <= 3 && cfg.init_ch <= 64 && last_coords != nullptr) {
+            // conv0 weight gradient from the hit list (bias gradient is exactly zero in exact arithmetic: BN0 follows)
+            StemWgradArgs sa{last_coords, last_nnz, ws + L.img, n, cfg.H, cfg.W, cfg.in_ch, e0, Hc, Wc, ef.Kp,
+                             reinterpret_cast<float*>(ws + L.slab), kSlabBytes};
+            if ((rc = stem_wgrad_sparse(sa, gw_of(s_w0), st))) return rc;
+        } else if ((rc = conv_wgrad(w, st))) return rc;
     }
     return unpack_wgrads(reinterpret_cast<const UnpackDesc*>(d_undesc), n_unpack, st);
 }

@@ -46,6 +46,7 @@ struct DenseNetPlan {
     char* d_desc = nullptr; size_t desc_cap = 0; std::vector<char> h_desc;
     char* desc_ws = nullptr; long desc_total = 0; int n_pack = 0, n_bneval = 0;
     uint64_t last_seed = 0; int last_n = 0;
+    const int32_t* last_coords = nullptr; long last_nnz = 0;     // COO list of the last forward (sparse stem weight gradient)
     char* d_undesc = nullptr; std::vector<char> h_undesc; char* undesc_ws = nullptr; long undesc_total = 0; int n_unpack = 0;
 
     explicit DenseNetPlan(const tcvn_densenet_cfg& c);

@@ -200,6 +200,17 @@ int eff_materialize_bf16(const EffMatArgs& a, hipStream_t st);
 struct ActPoolArgs { const void* X; long ldx; int n_img, Hin, Win, C; const float *sc, *sh, *sl; void* Out; long ldo; };
 int act_pool_bf16(const ActPoolArgs& a, hipStream_t st);
 
+// bf16 stem kernels (stem.hip)
+int pool0_bwd_vec_grid(int n_img, int Hin, int Win);
+bool pool0_bwd_vec_ok(const Pool0BwdArgs& a);
+int pool0_bwd_vec(const Pool0BwdArgs& a, hipStream_t st);
+struct StemWgradArgs {
+    const int* coords; long nnz; const void* img; int n_img, H, W, Cpix;   // COO hit list + the dense bf16 map [n,H,W,Cpix]
+    EffSrc e;                                                                // gradient of the conv0 output [n,Hc,Wc,N]
+    int Hc, Wc, Kp; float* slab; long slab_bytes;
+};
+int stem_wgrad_sparse(const StemWgradArgs& a, float* dWk, hipStream_t st);
+
 // kernel-layout fp32 weight gradients -> reference OIHW gradients (accumulate)
 struct UnpackDesc { const float* src; float* dst; int N, Cin, taps, Kp; int nfast; };   // nfast: src is [k][32]
 int unpack_wgrads(const UnpackDesc* d_descs, int n, hipStream_t st);

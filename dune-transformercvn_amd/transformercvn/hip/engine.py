@@ -106,6 +106,7 @@ class DenseNetEngine(_Plan):
         assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape == (n_img, self.out_dim)
         ws = self.workspace(self.workspace_bytes(n_img, train), coords.device)
         self._n = n_img
+        self._inputs = (coords, values)          # backward reads the COO list again (sparse stem weight gradient)
         check(lib.tcvn_densenet_forward(self.handle, n_img, _ptr(coords), _ptr(values), coords.shape[0], int(log_pixels),
                                         float(noise_std), _ptr(out), out.stride(0), _ptr(ws), ws.numel(), int(train),
                                         C.c_uint64(seed), _stream_ptr()), "densenet_forward")

@@ -214,7 +214,7 @@ class HipRuntime:
         if not (training and torch.is_grad_enabled()):
             return ev, pr
         state = dict(rows=rows, tok_row=tok_row, B=B, P=P, n_prongs=n_prongs, event_logits=ev, prong_logits=pr,
-                     feat=feat, pix=pix)
+                     feat=feat, pix=pix, keep=(event_px, prong_px))      # the COO lists are read again by backward
         return _FusedStep.apply(self.anchor, self, state)
 
     def _backward(self, st: dict, d_ev: Tensor, d_pr: Tensor):

@@ -62,7 +62,8 @@ int64_t tcvn_densenet_workspace_bytes(const tcvn_densenet* p, int n_img, int wit
  *   coords [nnz,3] int32 (image, y, x), values [nnz, in_ch] fp32 raw pixel values (reference:
  *   trainers/neutrino_full_dense_trainer.py:15-24,46-67: v/255 or log(v+1), optional multiplicative noise, COO->dense).
  *   out [n_img, out_dim] fp32 with row stride out_ld.
- *   train != 0: batch statistics, running-stat update, dropout (seed) -- and the workspace keeps what backward needs. */
+ *   train != 0: batch statistics, running-stat update, dropout (seed) -- and the workspace keeps what backward needs;
+ *   `coords` must stay valid until tcvn_densenet_backward has run (the stem weight gradient walks the hit list). */
 int tcvn_densenet_forward(tcvn_densenet* p, int n_img, const int32_t* coords, const float* values, int64_t nnz,
                           int log_pixels, float noise_std, float* out, int64_t out_ld, void* workspace,
                           int64_t workspace_bytes, int train, uint64_t seed, void* stream);
