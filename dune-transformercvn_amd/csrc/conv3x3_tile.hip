@@ -329,7 +329,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad_bf16(const ConvDgradAr
     const PadGeom q(n_img, g.H, g.W);
     const int nrows4 = (q.rows() + 3) & ~3;
     int* tbl = reinterpret_cast<int*>(smem + nrows4 * 64);                 // [nrows4] pixel index per image row
-    double* red = reinterpret_cast<double*>(smem);                          // [128][3] aliases the image after the last tile
+    constexpr int CLD3 = 132;
+    double* sred = reinterpret_cast<double*>(smem + nrows4 * 68);           // [128][3] per-channel sums of this workgroup
+    float* Cs = reinterpret_cast<float*>(smem + nrows4 * 68 + 128 * 24);    // [64][CLD3] fp32 dA tile (one pass)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -348,8 +350,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad_bf16(const ConvDgradAr
     bf16x8_t bw[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + i * 512);
-    const int c = wave * 32 + r;                                           // this lane's output channel
-    const float sc = g.sc[c], sh = g.sh[c], sl = g.sl[c];
+    const int e_c8 = tid & 15, e_r0 = tid >> 4;                            // epilogue role: 8-channel chunk, rows e_r0 + 16*i
+    float esc[8], esh[8], esl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { esc[j] = g.sc[e_c8 * 8 + j]; esh[j] = g.sh[e_c8 * 8 + j]; esl[j] = g.sl[e_c8 * 8 + j]; }
+    for (int i = tid; i < 128 * 3; i += 256) sred[i] = 0.0;
 
     const int ec = tid & 3, er0 = tid >> 2;                                // eff staging: chunk ec of rows er0, er0+64, ...
     float cP[8], cQ[8];
@@ -358,7 +363,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad_bf16(const ConvDgradAr
         const int n = ec * 8 + j;
         cP[j] = n < e.N ? e.P[n] : 0.f; cQ[j] = n < e.N ? e.Q[n] : 0.f;
     }
-    double s1 = 0, s2 = 0, s3 = 0;
     for (int t = lb; t < ntiles; t += nb) {
         const int g0 = t * TP;
         __syncthreads();
@@ -404,40 +408,58 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad_bf16(const ConvDgradAr
                 }
             }
         }
-        // epilogue: u = sc*y + sh ; dU = dA * prelu'(u) ; DU = sc*dU.  Sums: fp32 over 4 consecutive rows, fp64 beyond
-        // (the BatchNorm backward subtracts nearly equal sums, so the partials must be better than fp32)
+        // epilogue through LDS (two passes of 64 rows): the fp32 dA tile is re-read as 8-channel chunks so that Y is loaded and
+        // DU stored 16 B per lane; u = sc*y + sh ; dU = dA * prelu'(u) ; DU = sc*dU ; sums (dU, dU*y, dA*min(u,0)) per channel
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                float f1 = 0.f, f2 = 0.f, f3 = 0.f;
+            for (int half = 0; half < 2; ++half) {
+                const int mt = pass * 2 + half;
 #pragma unroll
-                for (int kr = 0; kr < 4; ++kr) {
-                    const int k = kq * 4 + kr;
-                    const int m = tbl[q.halo + mt * 32 + kr + 8 * kq + 4 * h];
-                    if (m >= 0) {
-                        const float y = bf2f(Y[(long)m * g.ldxin + c]);
-                        const float u = fmaf(y, sc, sh);
-                        const float dA = acc[mt][k];
-                        const float du = u > 0.f ? dA : sl * dA;
-                        f1 += du; f2 += du * y; f3 += u > 0.f ? 0.f : dA * u;
-                        DU[(long)m * g.ldgo + c] = f2bf(sc * du);
-                    }
-                }
-                s1 += (double)f1; s2 += (double)f2; s3 += (double)f3;
+                for (int k = 0; k < 16; ++k) Cs[(half * 32 + (k & 3) + 8 * (k >> 2) + 4 * h) * CLD3 + wave * 32 + r] = acc[mt][k];
             }
+            __syncthreads();
+            float f1[8], f2[8], f3[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { f1[j] = 0.f; f2[j] = 0.f; f3[j] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = e_r0 + 16 * i;
+                const int m = tbl[q.halo + pass * 64 + rr];
+                if (m >= 0) {
+                    const float4 ca = *reinterpret_cast<const float4*>(Cs + rr * CLD3 + e_c8 * 8);
+                    const float4 cc = *reinterpret_cast<const float4*>(Cs + rr * CLD3 + e_c8 * 8 + 4);
+                    const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cc.x, cc.y, cc.z, cc.w};
+                    const u16x8 yv = *reinterpret_cast<const u16x8*>(Y + (long)m * g.ldxin + e_c8 * 8);
+                    u16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = bf2f(yv[j]);
+                        const float u = fmaf(y, esc[j], esh[j]);
+                        const float du = u > 0.f ? cv[j] : esl[j] * cv[j];
+                        f1[j] += du; f2[j] += du * y; f3[j] += u > 0.f ? 0.f : cv[j] * u;
+                        o[j] = f2bf(esc[j] * du);
+                    }
+                    *reinterpret_cast<u16x8*>(DU + (long)m * g.ldgo + e_c8 * 8) = o;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(&sred[(e_c8 * 8 + j) * 3], (double)f1[j]);
+                atomicAdd(&sred[(e_c8 * 8 + j) * 3 + 1], (double)f2[j]);
+                atomicAdd(&sred[(e_c8 * 8 + j) * 3 + 2], (double)f3[j]);
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
-    if (lane < 32) { red[c * 3] = s1; red[c * 3 + 1] = s2; red[c * 3 + 2] = s3; }
     __syncthreads();
     if (tid < 128) {
         double* p = g.part + ((long)blockIdx.x * g.N + tid) * 3;
-        p[0] = red[tid * 3]; p[1] = red[tid * 3 + 1]; p[2] = red[tid * 3 + 2];
+        p[0] = sred[tid * 3]; p[1] = sred[tid * 3 + 1]; p[2] = sred[tid * 3 + 2];
     }
 }
 
-size_t dgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return r4 * 64 + r4 * 4 + 64; }
+size_t dgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return r4 * 68 + 128 * 24 + 64 * 132 * 4; }
 int tile_grid2(long ntiles) {           // two workgroups per CU
     if (ntiles >= 512) return 512;
     if (ntiles >= 8) return (int)(ntiles / 8 * 8);
@@ -544,7 +566,7 @@ bool conv3x3_dgrad_tile_ok(const ConvDgradArgs& a) {
     if (a.Wfrag == nullptr || a.accumulate || a.ldxin != 128 || a.ldgo != 128) return false;
     if ((a.e.ldg & 7) || (a.e.ldx & 7) || (a.e.c_off & 1) || a.M % (a.H * a.W) != 0) return false;
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
-    return q.gtot < (1L << 24) && q.rows() * 64 >= 128 * 24;
+    return q.gtot < (1L << 24);
 }
 int conv3x3_dgrad_tile_nblk(const ConvDgradArgs& a) {
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
