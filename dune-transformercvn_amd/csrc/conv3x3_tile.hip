@@ -15,6 +15,7 @@ using namespace t3;
 
 namespace {
 
+
 __device__ __forceinline__ int fdiv(int a, int d, float inv, int& rem) {     // a in [0, 2^24)
     int q = (int)((float)a * inv);
     rem = a - q * d;
@@ -117,9 +118,14 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_bf16(const ConvFwdArgs g
             }
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                // taps 0-6 keep their weights in AGPRs (16 acc + 224), taps 7-8 in arch VGPRs: no register copies
-                if (tap < 7) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af[tap & 1][ks]), "a"(bw[tap * 8 + ks]));
-                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af[tap & 1][ks]), "v"(bw[tap * 8 + ks]));
+                // taps 0-6 keep their weights in AGPRs (16 acc + 224), taps 7-8 in arch VGPRs.  hipcc's hazard recognizer does
+                // not see inside asm: the leading s_nop 1 covers (a) the two wait states gfx950 needs between a VALU write of an
+                // operand register (the allocator's v_accvgpr_read/v_mov copies land right in front of a statement) and the MFMA
+                // reading it, and (b) the wait state between back-to-back MFMAs chained through the accumulator.  Without it a
+                // wave occasionally (~1e-4 of tiles) computed a whole tile with one stale operand dword.  The nops are free:
+                // they sit in the shadow of the previous MFMA's 8 passes.
+                if (tap < 7) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af[tap & 1][ks]), "a"(bw[tap * 8 + ks]));
+                else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af[tap & 1][ks]), "v"(bw[tap * 8 + ks]));
             }
         }
         // the MFMAs sit inside asm statements: hipcc pads no hazard for them -- wait out the last MFMA's result latency
@@ -469,6 +475,8 @@ int tile_grid2(long ntiles) {           // two workgroups per CU
 size_t wgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return 2 * r4 * 256 + 2 * TP * 64 + 3 * r4 * 4; }
 
 int tile_grid(long ntiles) {            // one persistent workgroup per CU
+    static const int dbg = getenv("TCVN_DBG") ? atoi(getenv("TCVN_DBG")) : 0;
+    if (dbg & 16) return (int)ntiles;                 // debug: one tile per workgroup
     if (ntiles >= 256) return 256;
     if (ntiles >= 8) return (int)(ntiles / 8 * 8);
     return (int)ntiles;
@@ -513,7 +521,7 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
     ConvFwdArgs b = a;
     static const int dbg = getenv("TCVN_DBG") ? atoi(getenv("TCVN_DBG")) : 0;
     b.dbg = dbg;
-    hipLaunchKernelGGL(k_conv3x3_fwd_bf16, dim3(nb), dim3(256), smem, st, b, n_img, ntiles, (nb >= 8 && nb % 8 == 0) ? 1 : 0);
+    hipLaunchKernelGGL(k_conv3x3_fwd_bf16, dim3(nb), dim3(256), smem, st, b, n_img, ntiles, (nb >= 8 && nb % 8 == 0 && !(dbg & 8)) ? 1 : 0);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

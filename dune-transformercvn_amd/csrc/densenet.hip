@@ -129,11 +129,11 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
         std::vector<long> xas;
         for (int l = 0; l < bg.L; ++l) {
             const int cin = bg.C0 + l * cfg.growth;
-            xas.push_back((cfg.mode == MODE_BF16 && cin % 8 == 0) ? b.take(M * cin * esz) : -1);
+            xas.push_back(fast1_ok(cin) ? b.take(M * round_up(cin, 8) * esz) : -1);    // row stride round_up(cin, 8), zero padded
         }
         L.XA.push_back(xas);
-        const bool tfast = cfg.mode == MODE_BF16 && bg.has_trans && bg.Ctot % 16 == 0;
-        L.XP.push_back(tfast ? b.take((long)n * (bg.H / 2) * (bg.W / 2) * bg.Ctot * esz) : -1);
+        const bool tfast = bg.has_trans && fastt_ok(bg.Ctot);
+        L.XP.push_back(tfast ? b.take((long)n * (bg.H / 2) * (bg.W / 2) * bg.ld * esz) : -1);   // row stride bg.ld, zero padded
         L.bstatD.push_back(b.take((long)bg.ld * 16));
         max_part = std::max(max_part, 512L * std::max(mid, bg.Ctot) * 16);   // every conv launcher uses <= 512 workgroups
         maxY = std::max(maxY, M * mid);
@@ -185,6 +185,16 @@ long DenseNetPlan::wk_bytes() const {
     long t = 0;
     for (const auto& w : wk_list()) t += round_up(round_up(w.rows, 32) * w.Kp * esz, 256);
     return t;
+}
+
+// bf16 GEMM paths for the 1x1 convolutions: operands are materialised with row strides rounded up to 8 channels (zero
+// padded), so any channel count works as long as the K extent fits the NT kernel's register-resident weights (<= 640).
+bool DenseNetPlan::fast1_ok(int cin) const {
+    const int mid = cfg.bn_size * cfg.growth;
+    return cfg.mode == MODE_BF16 && conv3x3_tile_enabled() && mid % 8 == 0 && mid <= 256 && round_up(cin, 32) <= 640;
+}
+bool DenseNetPlan::fastt_ok(int Ctot) const {
+    return cfg.mode == MODE_BF16 && conv3x3_tile_enabled() && round_up(Ctot, 32) <= 640 && Ctot / 2 <= 512;
 }
 
 // every conv weight in kernel layout; the order defines the offsets in the wk region
@@ -367,16 +377,17 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         for (int l = 0; l < bg.L; ++l) {
             const LayerSlots& ls = bg.layers[l];
             if ((rc = link(ls.n1, part, new_nblk, new_ld, new_c0, new_n, bstatD, M))) return rc;
-            const bool fast1 = L.XA[bi][l] >= 0 && conv3x3_tile_enabled() && mid % 8 == 0 && ls.cin <= 512;
+            const bool fast1 = L.XA[bi][l] >= 0;
+            const int cin8 = (int)round_up(ls.cin, 8);
             if (fast1) {     // activated copy of the 1x1 input: operand of the bf16 GEMMs (forward and weight gradient)
                 Tab t1 = tab(ls.n1);
-                ActArgs act{D, bg.ld, M, ls.cin, t1.sc, t1.sh, data[ls.a1], ws + L.XA[bi][l], ls.cin};
+                ActArgs act{D, bg.ld, M, ls.cin, t1.sc, t1.sh, data[ls.a1], ws + L.XA[bi][l], cin8};
                 if ((rc = act_bf16(act, st))) return rc;
             }
             if (fast1) {   // bottleneck 1x1 on the NT GEMM: XA x W1^T -> Y
                 const WkEntry& e = wk_find(ls.w1, 0, 1);
                 GemmNtArgs a{};
-                a.epi = EPI_FWD; a.A = ws + L.XA[bi][l]; a.lda = ls.cin; a.K = ls.cin; a.M = M; a.N = mid;
+                a.epi = EPI_FWD; a.A = ws + L.XA[bi][l]; a.lda = cin8; a.K = cin8; a.M = M; a.N = mid;
                 a.Wfrag = ws + L.wk + e.off; a.Kp = e.Kp; a.zeros = ws + L.zeros; a.bias = data[ls.b1];
                 a.Out = ws + L.Y[bi][l]; a.ldo = mid; a.n_off = 0; a.part = train ? part : nullptr; a.nblk = gemm_nt_nblk(a);
                 if ((rc = gemm_nt_bf16(a, "k_gemm_nt_bf16<fwd1x1>", st))) return rc;
@@ -418,15 +429,15 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             const WkEntry& e = wk_find(bg.tw, 0);
             Tab t = tab(bg.tn);
             const long Mn = (long)n * nb.H * nb.W;
-            const bool fastt = L.XP[bi] >= 0 && conv3x3_tile_enabled() && bg.Ctot <= 512;
+            const bool fastt = L.XP[bi] >= 0;
             if (fastt) {
-                ActPoolArgs ap{D, bg.ld, n, bg.H, bg.W, bg.Ctot, t.sc, t.sh, data[bg.ta], ws + L.XP[bi], bg.Ctot};
+                ActPoolArgs ap{D, bg.ld, n, bg.H, bg.W, bg.Ctot, t.sc, t.sh, data[bg.ta], ws + L.XP[bi], bg.ld};
                 if ((rc = act_pool_bf16(ap, st))) return rc;
             }
             if (fastt) {
                 const WkEntry& ef = wk_find(bg.tw, 0, 1);
                 GemmNtArgs ga{};
-                ga.epi = EPI_FWD; ga.A = ws + L.XP[bi]; ga.lda = bg.Ctot; ga.K = bg.Ctot; ga.M = Mn; ga.N = bg.Ctot / 2;
+                ga.epi = EPI_FWD; ga.A = ws + L.XP[bi]; ga.lda = bg.ld; ga.K = bg.ld; ga.M = Mn; ga.N = bg.Ctot / 2;
                 ga.Wfrag = ws + L.wk + ef.off; ga.Kp = ef.Kp; ga.zeros = ws + L.zeros; ga.bias = data[bg.tb];
                 ga.Out = ws + L.D[bi + 1]; ga.ldo = nb.ld; ga.n_off = 0; ga.part = train ? part : nullptr; ga.nblk = gemm_nt_nblk(ga);
                 if ((rc = gemm_nt_bf16(ga, "k_gemm_nt_bf16<fwdtrans>", st))) return rc;
@@ -470,6 +481,13 @@ int DenseNetPlan::tap(int n, const char* name, long* off, int* tn, int* th, int*
     *tn = n; *tes = esz;
     if (s == "conv0") { *off = L.c0; *th = Hc; *tw = Wc; *tc = cfg.init_ch; *tld = cfg.init_ch; return 0; }
     if (s == "condense") { *off = L.F; *th = 1; *tw = 1; *tc = Cf; *tld = Cf; *tes = 4; return 0; }
+    if (s == "raw:wk") { *tn = *th = *tw = 1; *off = L.wk; *tc = *tld = (int)(wk_bytes() / esz); return 0; }
+    if (s == "raw:tabs") { *tn = *th = *tw = 1; *off = L.tabs; *tc = *tld = (int)tab_floats(); *tes = 4; return 0; }
+    if (s.rfind("raw:bstat", 0) == 0) {
+        const int b = atoi(s.c_str() + 9) - 1;
+        if (b < 0 || b >= (int)blocks.size()) return -1;
+        *tn = *th = *tw = 1; *off = L.bstatD[b]; *tc = *tld = blocks[b].ld * 2; *tes = 8; return 0;
+    }
     if (s.rfind("dense", 0) == 0) {
         const int b = atoi(s.c_str() + 5) - 1;
         if (b < 0 || b >= (int)blocks.size()) return -1;
@@ -482,6 +500,17 @@ int DenseNetPlan::tap(int n, const char* name, long* off, int* tn, int* th, int*
         b -= 1;
         if (b < 0 || b >= (int)blocks.size() || l < 0 || l >= blocks[b].L) return -1;
         *off = L.Y[b][l]; *th = blocks[b].H; *tw = blocks[b].W; *tc = cfg.bn_size * cfg.growth; *tld = *tc;
+        return 0;
+    }
+    if (s.rfind("xa", 0) == 0 || s.rfind("ya", 0) == 0) {      // bf16 mode: materialised activations (1x1 / 3x3 operands)
+        int b = 0, l = 0;
+        if (sscanf(s.c_str() + 2, "%d.%d", &b, &l) != 2) return -1;
+        b -= 1;
+        if (b < 0 || b >= (int)blocks.size() || l < 0 || l >= blocks[b].L) return -1;
+        const bool xa = s[0] == 'x';
+        if ((xa && (L.XA[b].empty() || L.XA[b][l] < 0)) || (!xa && L.YA[b].empty())) return -1;
+        *off = xa ? L.XA[b][l] : L.YA[b][l]; *th = blocks[b].H; *tw = blocks[b].W;
+        *tc = xa ? blocks[b].layers[l].cin : cfg.bn_size * cfg.growth; *tld = xa ? (int)round_up(*tc, 8) : *tc;
         return 0;
     }
     return -1;

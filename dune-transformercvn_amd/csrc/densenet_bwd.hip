@@ -150,18 +150,19 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             w.fa.mode = mode; w.fa.amode = A_1X1_POOL; w.fa.A = D; w.fa.lda = bg.ld; w.fa.M = (int)Mn; w.fa.N = Nt;
             w.fa.K = bg.Ctot; w.fa.Kp = ef.Kp; w.fa.C = bg.Ctot; w.fa.H = nb.H; w.fa.W = nb.W; w.fa.Hin = bg.H; w.fa.Win = bg.W;
             w.fa.sc = sc_of(bg.tn); w.fa.sh = sh_of(bg.tn); w.fa.sl = data[bg.ta];
-            if (L.XP[bi] >= 0 && conv3x3_tile_enabled() && bg.Ctot <= 512) {
+            const int Nt8 = (int)round_up(Nt, 8);
+            if (L.XP[bi] >= 0) {
                 // materialise the output gradient once (+ bias gradient), then dW = ET^T x XP on the TN GEMM
-                EffMatArgs em{e, Mn, ws + L.ey, Nt, grad[bg.tb], reinterpret_cast<float*>(ws + L.slab)};
+                EffMatArgs em{e, Mn, ws + L.ey, Nt8, grad[bg.tb], reinterpret_cast<float*>(ws + L.slab)};
                 if ((rc = eff_materialize_bf16(em, st))) return rc;
-                GemmTnArgs ga{ws + L.ey, Nt, Nt, ws + L.XP[bi], bg.Ctot, bg.Ctot, Mn, gw_of(bg.tw), ef.Kp, ws + L.zeros,
-                              reinterpret_cast<float*>(ws + L.slab), kSlabBytes};
+                GemmTnArgs ga{ws + L.ey, Nt8, Nt8, ws + L.XP[bi], bg.ld, bg.ld, Mn, gw_of(bg.tw), ef.Kp, ws + L.zeros,
+                              reinterpret_cast<float*>(ws + L.slab), kSlabBytes, Nt};
                 if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<transition>", st))) return rc;
             } else if ((rc = conv_wgrad(w, st))) return rc;
-            if (L.XP[bi] >= 0 && conv3x3_tile_enabled() && bg.Ctot <= 512) {
+            if (L.XP[bi] >= 0) {
                 const WkEntry& etf = wk_find(bg.tw, 1, 1);
                 GemmNtArgs ga{};
-                ga.epi = EPI_DGRAD_POOL; ga.A = ws + L.ey; ga.lda = Nt; ga.K = Nt; ga.M = Mn; ga.N = bg.Ctot;
+                ga.epi = EPI_DGRAD_POOL; ga.A = ws + L.ey; ga.lda = Nt8; ga.K = Nt8; ga.M = Mn; ga.N = bg.Ctot;
                 ga.Wfrag = ws + L.wk + etf.off; ga.Kp = etf.Kp; ga.zeros = ws + L.zeros;
                 ga.Xin = D; ga.ldxin = bg.ld; ga.sc = sc_of(bg.tn); ga.sh = sh_of(bg.tn); ga.sl = data[bg.ta];
                 ga.Gout = G; ga.ldgo = bg.ld; ga.H = nb.H; ga.W = nb.W; ga.Hin = bg.H; ga.Win = bg.W;
@@ -221,15 +222,16 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 w.fa.mode = mode; w.fa.amode = A_1X1; w.fa.A = D; w.fa.lda = bg.ld; w.fa.M = (int)M; w.fa.N = mid; w.fa.K = ls.cin;
                 w.fa.Kp = ef.Kp; w.fa.C = ls.cin; w.fa.H = bg.H; w.fa.W = bg.W;
                 w.fa.sc = sc_of(ls.n1); w.fa.sh = sh_of(ls.n1); w.fa.sl = data[ls.a1];
-                if (L.XA[bi][l] >= 0 && conv3x3_tile_enabled() && ls.cin <= 512) {
+                if (L.XA[bi][l] >= 0) {
                     EffMatArgs em{e1, M, ws + L.ey, mid, grad[ls.b1], reinterpret_cast<float*>(ws + L.slab)};
                     if ((rc = eff_materialize_bf16(em, st))) return rc;
-                    GemmTnArgs ga{ws + L.ey, mid, mid, ws + L.XA[bi][l], ls.cin, ls.cin, M, gw_of(ls.w1), ef.Kp, ws + L.zeros,
-                                  reinterpret_cast<float*>(ws + L.slab), kSlabBytes};
+                    const int cin8 = (int)round_up(ls.cin, 8);
+                    GemmTnArgs ga{ws + L.ey, mid, mid, ws + L.XA[bi][l], cin8, cin8, M, gw_of(ls.w1), ef.Kp, ws + L.zeros,
+                                  reinterpret_cast<float*>(ws + L.slab), kSlabBytes, mid};
                     if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<conv1>", st))) return rc;
                 } else if ((rc = conv_wgrad(w, st))) return rc;
             }
-            if (L.XA[bi][l] >= 0 && conv3x3_tile_enabled() && ls.cin <= 512) {   // conv1 data gradient on the NT GEMM (A = EY)
+            if (L.XA[bi][l] >= 0) {   // conv1 data gradient on the NT GEMM (A = EY)
                 const WkEntry& etf = wk_find(ls.w1, 1, 1);
                 GemmNtArgs ga{};
                 ga.epi = EPI_DGRAD; ga.A = ws + L.ey; ga.lda = mid; ga.K = mid; ga.M = M; ga.N = ls.cin;

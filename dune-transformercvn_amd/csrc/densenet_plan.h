@@ -41,6 +41,8 @@ struct DenseNetPlan {
     BnSlots n0, nf, nl;
     std::vector<WkEntry> wk_cache;
     bool bound = false;
+    bool fast1_ok(int cin) const;    // 1x1 bottleneck conv on the bf16 NT/TN GEMMs
+    bool fastt_ok(int Ctot) const;   // transition conv on the bf16 NT/TN GEMMs
     bool fast3x3 = false;            // bf16 padded-tile 3x3 kernels in use (decided at bind time)
     // device descriptor table (pack + eval BN descriptors)
     char* d_desc = nullptr; size_t desc_cap = 0; std::vector<char> h_desc;

@@ -147,15 +147,16 @@ __global__ void k_head_pool(const HeadPoolArgs a) {
 __global__ __launch_bounds__(256) void k_act_bf16(const ActArgs a) {
     const bf16* X = reinterpret_cast<const bf16*>(a.X);
     bf16* O = reinterpret_cast<bf16*>(a.Out);
-    const int cpr = a.C >> 3;                                  // chunks per row
+    const int cpr = (a.C + 7) >> 3;                            // chunks per row; the tail chunk is zero padded in Out
     const long total = (long)a.M * cpr;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long m = i / cpr;
         const int c = (int)(i - m * cpr) * 8;
-        const u16x8 v = *reinterpret_cast<const u16x8*>(X + m * a.ldx + c);
+        const u16x8 v = *reinterpret_cast<const u16x8*>(X + m * a.ldx + c);      // row stride ldx >= round_up(C, 8)
         u16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j]));
+        for (int j = 0; j < 8; ++j)
+            o[j] = c + j < a.C ? f2bf(prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j])) : (bf16)0;
         *reinterpret_cast<u16x8*>(O + m * a.ldo + c) = o;
     }
 }
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void k_act_bf16(const ActArgs a) {
 __global__ __launch_bounds__(256) void k_act_pool_bf16(const ActPoolArgs a) {
     const bf16* X = reinterpret_cast<const bf16*>(a.X);
     bf16* O = reinterpret_cast<bf16*>(a.Out);
-    const int Ho = a.Hin / 2, Wo = a.Win / 2, cpr = a.C >> 3;
+    const int Ho = a.Hin / 2, Wo = a.Win / 2, cpr = (a.C + 7) >> 3;
     const long total = (long)a.n_img * Ho * Wo * cpr;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long mo = i / cpr;
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(256) void k_act_pool_bf16(const ActPoolArgs a) {
         for (int t = 0; t < 4; ++t) {
             const u16x8 v = *reinterpret_cast<const u16x8*>(X + (p00 + (t >> 1) * a.Win + (t & 1)) * a.ldx + c);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j]);
+            for (int j = 0; j < 8; ++j)
+                if (c + j < a.C) acc[j] += prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j]);
         }
         u16x8 o;
 #pragma unroll
@@ -268,8 +270,8 @@ int head_pool_fwd(const HeadPoolArgs& a, hipStream_t st) {
 }
 
 int act_bf16(const ActArgs& a, hipStream_t st) {
-    if ((a.C & 7) || (a.ldx & 7) || (a.ldo & 7)) return -2;
-    const long total = (long)a.M * (a.C >> 3);
+    if ((a.ldx & 7) || (a.ldo & 7) || a.ldx < ((a.C + 7) & ~7) || a.ldo < ((a.C + 7) & ~7)) return -2;
+    const long total = (long)a.M * ((a.C + 7) >> 3);
     const long g = (total + 255) / 256;
     hipLaunchKernelGGL(k_act_bf16, dim3((unsigned)(g < 4096 ? g : 4096)), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
@@ -277,8 +279,8 @@ int act_bf16(const ActArgs& a, hipStream_t st) {
 }
 
 int act_pool_bf16(const ActPoolArgs& a, hipStream_t st) {
-    if ((a.C & 7) || (a.ldx & 7) || (a.ldo & 7)) return -2;
-    const long total = (long)a.n_img * (a.Hin / 2) * (a.Win / 2) * (a.C >> 3);
+    if ((a.ldx & 7) || (a.ldo & 7) || a.ldx < ((a.C + 7) & ~7) || a.ldo < ((a.C + 7) & ~7)) return -2;
+    const long total = (long)a.n_img * (a.Hin / 2) * (a.Win / 2) * ((a.C + 7) >> 3);
     const long g = (total + 255) / 256;
     hipLaunchKernelGGL(k_act_pool_bf16, dim3((unsigned)(g < 4096 ? g : 4096)), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a, int wlog) {
     const EffSrc& e = a.e;
     const int W = 1 << wlog, rpb = 256 >> wlog;
     const int tx = threadIdx.x & (W - 1), ty = threadIdx.x >> wlog;
-    const int cpr = e.N >> 3;
+    const int cpr = (e.N + 7) >> 3;                        // the tail chunk is zero padded in Out
     const bf16* G = reinterpret_cast<const bf16*>(e.G);
     const bf16* X = reinterpret_cast<const bf16*>(e.X);
     bf16* O = reinterpret_cast<bf16*>(a.Out);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a, int wlog) {
     if (tx < cpr) {
         float cP[8], cQ[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { cP[j] = e.P[tx * 8 + j]; cQ[j] = e.Q[tx * 8 + j]; }
+        for (int j = 0; j < 8; ++j) { const bool ok = tx * 8 + j < e.N; cP[j] = ok ? e.P[tx * 8 + j] : 0.f; cQ[j] = ok ? e.Q[tx * 8 + j] : 0.f; }
         const uint32_t dkey = drop_key(e.seed, e.stream_id);
         for (long m = (long)blockIdx.x * rpb + ty; m < a.M; m += (long)gridDim.x * rpb) {
             const u16x8 gv = *reinterpret_cast<const u16x8*>(G + m * e.ldg + e.c_off + tx * 8);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a, int wlog) {
             u16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float t = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
+                float t = tx * 8 + j < e.N ? bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j] : 0.f;
                 if (e.drop_p > 0.f) t *= drop_pick(drop_bits(dkey, m, tx * 8 + j, e.N), m, e.drop_p);
                 o[j] = f2bf(t);
                 cs[j] += bf2f(o[j]);
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a, int wlog) {
         for (int j = 0; j < 8; ++j) {
             float sum = 0.f;
             for (int q = 0; q < rpb; ++q) sum += red[q * W + tx][j];
-            a.slab[(long)blockIdx.x * e.N + tx * 8 + j] = sum;       // reduced by k_slab_reduce (same-line atomics serialise)
+            if (tx * 8 + j < e.N) a.slab[(long)blockIdx.x * e.N + tx * 8 + j] = sum;       // reduced by k_slab_reduce (same-line atomics serialise)
         }
     }
 }
@@ -238,9 +238,9 @@ int pool0_bwd(const Pool0BwdArgs& a, hipStream_t st) {
 int eff_materialize_bf16(const EffMatArgs& a, hipStream_t st) {
     if (a.M <= 0) return 0;
     const EffSrc& e = a.e;
-    if ((e.N & 7) || e.N > 512 || (e.ldg & 7) || (e.ldx & 7) || (e.c_off & 7) || (a.ldo & 7)) return -2;
+    if (e.N > 512 || (e.ldg & 7) || (e.ldx & 7) || (e.c_off & 7) || (a.ldo & 7) || a.ldo < ((e.N + 7) & ~7)) return -2;
     int wlog = 0;
-    while ((1 << wlog) < (e.N >> 3)) ++wlog;
+    while ((1 << wlog) < ((e.N + 7) >> 3)) ++wlog;
     const int rpb = 256 >> wlog;
     const long g = (a.M + rpb - 1) / rpb;
     const int nb = (int)(g < 1024 ? g : 1024);

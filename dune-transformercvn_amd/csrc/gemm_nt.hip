@@ -15,7 +15,7 @@ namespace tcvn {
 namespace {
 
 constexpr int ROWS = 128, CLD = 132;            // C tile leading dimension (floats), padded
-constexpr int MAXKS = 32;                       // k-steps of 16 held in registers (K <= 512)
+constexpr int KS_FWD = 40, KS_FWD_SMALL = 16, KS_DGRAD = 16, KS_POOL = 24;   // k-steps of 16 held in registers per instance
 
 __device__ __forceinline__ void dma_a(char* smem_base, int buf_off, const bf16* __restrict__ A, long lda, int K, int k0, long m0,
                                       long M, const char* __restrict__ zeros, int wave, int lane) {
@@ -32,7 +32,7 @@ __device__ __forceinline__ void dma_a(char* smem_base, int buf_off, const bf16* 
     }
 }
 
-template <int EPI>
+template <int EPI, int MAXKS>
 __global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = ROWS * 256;
@@ -61,14 +61,15 @@ __global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
     // epilogue role: 16 threads per row (8 channels each), rows c_r0 + 16*i
     const int c8 = tid & 15, c_r0 = tid >> 4;
     const int ncol = n0 + c8 * 8;                                         // first output column of this thread's chunk
-    const bool col_ok = ncol < g.N;                                        // N % 8 == 0
+    const bool col_ok = ncol < g.N;                                        // the last chunk may be partial (N % 8 != 0)
     float cb[8], csc[8], csh[8], csl[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        cb[j] = (EPI == EPI_FWD && col_ok) ? g.bias[ncol + j] : 0.f;
-        csc[j] = (EPI != EPI_FWD && col_ok) ? g.sc[ncol + j] : 0.f;
-        csh[j] = (EPI != EPI_FWD && col_ok) ? g.sh[ncol + j] : 0.f;
-        csl[j] = (EPI != EPI_FWD && col_ok) ? g.sl[ncol + j] : 0.f;
+        const bool ok = ncol + j < g.N;
+        cb[j] = (EPI == EPI_FWD && ok) ? g.bias[ncol + j] : 0.f;
+        csc[j] = (EPI != EPI_FWD && ok) ? g.sc[ncol + j] : 0.f;
+        csh[j] = (EPI != EPI_FWD && ok) ? g.sh[ncol + j] : 0.f;
+        csl[j] = (EPI != EPI_FWD && ok) ? g.sl[ncol + j] : 0.f;
     }
     double st1[8], st2[8], st3[8];
 #pragma unroll
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
                         u16x8 o;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            o[j] = f2bf(cv[j] + cb[j]);
+                            o[j] = ncol + j < g.N ? f2bf(cv[j] + cb[j]) : (bf16)0;     // channels beyond N: zero (written later)
                             const float x = bf2f(o[j]);
                             f1[j] += x; f2[j] += x * x;
                         }
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
                                     const float dA = EPI == EPI_DGRAD_POOL ? 0.25f * cv[j] : cv[j];
                                     const float du = u > 0.f ? dA : csl[j] * dA;
                                     f1[j] += du; f2[j] += du * x; f3[j] += u > 0.f ? 0.f : dA * u;
-                                    o[j] = f2bf(bf2f(gv[j]) + csc[j] * du);
+                                    o[j] = ncol + j < g.N ? f2bf(bf2f(gv[j]) + csc[j] * du) : gv[j];   // beyond N: not ours
                                 }
                                 *reinterpret_cast<u16x8*>(gp) = o;
                             }
@@ -203,8 +204,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
 
 }  // namespace
 
+static int nt_max_ksteps(int epi) { return epi == EPI_FWD ? KS_FWD : epi == EPI_DGRAD ? KS_DGRAD : KS_POOL; }
 bool gemm_nt_ok(const GemmNtArgs& a) {
-    if (!a.A || !a.Wfrag || !a.zeros || (a.lda & 7) || (a.K & 7) || (a.N & 7) || a.Kp > MAXKS * 16 || (a.Kp & 15)) return false;
+    if (!a.A || !a.Wfrag || !a.zeros || (a.lda & 7) || (a.K & 7) || a.Kp > nt_max_ksteps(a.epi) * 16 || (a.Kp & 15)) return false;
     if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.Wfrag) & 15)) return false;
     if (a.epi == EPI_FWD) return (a.ldo & 7) == 0 && (a.n_off & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Out) & 15) == 0;
     return (a.ldxin & 7) == 0 && (a.ldgo & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Xin) & 15) == 0 &&
@@ -221,16 +223,19 @@ int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
     const size_t smem = 2 * ROWS * 256 + (size_t)ROWS * CLD * 4;
     static bool attr = false;
     if (!attr) {
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD_POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const void* fns[4] = {reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL>)};
+        for (const void* f : fns) TCVN_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     ProfScope ps(label, 2.0 * a.M * (double)a.N * a.K, 0.0, st);
     const dim3 grid(gemm_nt_nblk(a), cdiv(a.N, 128));
-    if (a.epi == EPI_FWD) hipLaunchKernelGGL(k_gemm_nt_bf16<EPI_FWD>, grid, dim3(256), smem, st, a);
-    else if (a.epi == EPI_DGRAD) hipLaunchKernelGGL(k_gemm_nt_bf16<EPI_DGRAD>, grid, dim3(256), smem, st, a);
-    else hipLaunchKernelGGL(k_gemm_nt_bf16<EPI_DGRAD_POOL>, grid, dim3(256), smem, st, a);
+    if (a.epi == EPI_FWD && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL>), grid, dim3(256), smem, st, a);
+    else if (a.epi == EPI_FWD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD>), grid, dim3(256), smem, st, a);
+    else if (a.epi == EPI_DGRAD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD>), grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL>), grid, dim3(256), smem, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_tn_bf16(const GemmTnArgs g, lon
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int i = i0 + wi * 64 + ta * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (i < g.Li) g.slab[((long)blockIdx.z * g.Li + i) * g.ldc + j] = acc[ta][tb][e];
+                if (i < g.Ci) g.slab[((long)blockIdx.z * g.Ci + i) * g.ldc + j] = acc[ta][tb][e];
             }
         }
 }
@@ -138,13 +138,13 @@ int gemm_tn_bf16(const GemmTnArgs& a, const char* label, hipStream_t st) {
         TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    if (a.slab == nullptr || (long)split * a.Li * a.ldc * 4 > a.slab_bytes || cdiv(a.ldc, 128) > jt) return -3;
+    if (a.slab == nullptr || a.Ci <= 0 || a.Ci > a.Li || (long)split * a.Ci * a.ldc * 4 > a.slab_bytes || cdiv(a.ldc, 128) > jt) return -3;
     {
         ProfScope ps(label, 2.0 * a.M * (double)a.Li * a.Rj, 0.0, st);
         hipLaunchKernelGGL(k_gemm_tn_bf16, dim3(jt, it, split), dim3(256), 4 * ROWS * 256, st, a, rows);
         TCVN_LAUNCH_CHECK();
     }
-    return slab_reduce(a.slab, split, (long)a.Li * a.ldc, a.C, st);
+    return slab_reduce(a.slab, split, (long)a.Ci * a.ldc, a.C, st);
 }
 
 }  // namespace tcvn

@@ -167,7 +167,8 @@ int pool0_bwd_grid(int n_img, int Hin, int Win);
 
 // bf16 TN GEMM over pixels (gemm_tn.hip): C[i][j] += sum_m L[m][i] * R[m][j]
 struct GemmTnArgs { const void* L; long ldl; int Li; const void* R; long ldr; int Rj; long M; float* C; long ldc; const void* zeros;
-                    float* slab; long slab_bytes; };     // slab: scratch for per-slice partial tiles (no contended atomics)
+                    float* slab; long slab_bytes;        // slab: scratch for per-slice partial tiles (no contended atomics)
+                    int Ci; };                           // rows of C written (<= Li; L columns in [Ci, Li) are zero padding)
 // dst[i] += sum_s slab[s*count + i]   (deterministic reduction of per-workgroup partial results)
 int slab_reduce(const float* slab, int nslab, long count, float* dst, hipStream_t st, long stride = 0);   // stride 0 = count
 bool gemm_tn_ok(const GemmTnArgs& a);
@@ -178,7 +179,7 @@ enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_DGRAD_POOL = 2 };
 struct GemmNtArgs {
     int epi;
     const void* A; long lda; int K;          // [M][lda] bf16, K columns used
-    long M; int N;                           // output columns (multiple of 8)
+    long M; int N;                           // output columns (any count; 8-column chunks, the tail chunk is masked)
     const void* Wfrag; int Kp;               // weights [N][Kp] in MFMA fragment order
     const void* zeros;
     const float* bias; void* Out; long ldo; int n_off;             // EPI_FWD

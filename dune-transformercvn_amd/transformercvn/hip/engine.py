@@ -122,7 +122,7 @@ class DenseNetEngine(_Plan):
         off, n, h, w, c, ld, es = C.c_int64(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(lib.tcvn_densenet_tap(self.handle, self._n, name.encode(), C.byref(off), C.byref(n), C.byref(h), C.byref(w),
                                     C.byref(c), C.byref(ld), C.byref(es)), f"tap {name}")
-        dt = torch.float32 if es.value == 4 else torch.bfloat16
+        dt = {8: torch.float64, 4: torch.float32}.get(es.value, torch.bfloat16)
         raw = self._ws[off.value: off.value + n.value * h.value * w.value * ld.value * es.value].view(dt)
         return raw.view(n.value, h.value, w.value, ld.value)[..., :c.value]
 
