@@ -154,9 +154,14 @@ __global__ __launch_bounds__(256) void k_act_bf16(const ActArgs a) {
         const int c = (int)(i - m * cpr) * 8;
         const u16x8 v = *reinterpret_cast<const u16x8*>(X + m * a.ldx + c);      // row stride ldx >= round_up(C, 8)
         u16x8 o;
+        if (c + 8 <= a.C) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            o[j] = c + j < a.C ? f2bf(prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j])) : (bf16)0;
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j]));
+        } else {                                               // tail chunk of a row: channels >= C are written as zeros
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j] = c + j < a.C ? f2bf(prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j])) : (bf16)0;
+        }
         *reinterpret_cast<u16x8*>(O + m * a.ldo + c) = o;
     }
 }
@@ -175,12 +180,22 @@ __global__ __launch_bounds__(256) void k_act_pool_bf16(const ActPoolArgs a) {
         const long img = mo / ((long)Wo * Ho);
         const long p00 = (img * a.Hin + 2 * ho) * a.Win + 2 * wo;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float sc[8], sh[8], sl[8];
+        if (c + 8 <= a.C) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sc[j] = a.sc[c + j]; sh[j] = a.sh[c + j]; sl[j] = a.sl[c + j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const bool ok = c + j < a.C; sc[j] = ok ? a.sc[c + j] : 0.f; sh[j] = ok ? a.sh[c + j] : 0.f; sl[j] = ok ? a.sl[c + j] : 0.f; }
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const u16x8 v = *reinterpret_cast<const u16x8*>(X + (p00 + (t >> 1) * a.Win + (t & 1)) * a.ldx + c);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (c + j < a.C) acc[j] += prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j]);
+            for (int j = 0; j < 8; ++j) {
+                const float y = prelu(fmaf(bf2f(v[j]), sc[j], sh[j]), sl[j]);
+                acc[j] += c + j < a.C ? y : 0.f;              // channels >= C may hold anything (never written): select, not multiply
+            }
         }
         u16x8 o;
 #pragma unroll
