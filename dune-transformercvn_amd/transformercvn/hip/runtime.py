@@ -81,7 +81,6 @@ class HipRuntime:
         self.flat_param = self.flat_grad = self.flat_buf = None
         self._sig = None
         self._grad_views: List[Tensor] = []
-        self._bn_counters: List[Tensor] = []
         self.grad_ready_hook = None          # called as hook(tag) when a gradient segment is final ("head", "event", "prong")
         self.segments: Dict[str, Tuple[int, int]] = {}
 
@@ -163,6 +162,7 @@ class HipRuntime:
                for m in mod.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
         # num_batches_tracked of every BatchNorm become views of one int64 arena: one add per step instead of 139
         all_bn = [m for m in net.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
+        self._side = torch.cuda.Stream(dev)          # event-embedder stream (forward/_backward)
         self.flat_nbt = torch.stack([m.num_batches_tracked.to(dev) for m in all_bn]).contiguous()
         ran_ids = {id(m) for m in ran}
         self._nbt_inc = torch.tensor([1 if id(m) in ran_ids else 0 for m in all_bn], dtype=torch.int64, device=dev)
@@ -210,10 +210,16 @@ class HipRuntime:
         with torch.no_grad():
             rows = torch.zeros(B + n_prongs, in_dim, device=dev)
             rows[:, feat + pix:] = self._pos            # prongs also get the *event* position embedding (reference quirk)
-            self.ev_engine.forward(event_px.coords, event_px.values, B, rows[:B, :feat + pix], training, seed ^ 0x1111,
-                                   event_px.value_mode, event_px.noise_std if training else 0.0)
+            # the two embedders are independent until the token path: the small event DenseNet (B images) runs on a side
+            # stream underneath the prong DenseNet (n_prongs images), whose launches alone do not fill the chip in the deep blocks
+            main = torch.cuda.current_stream(dev)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                self.ev_engine.forward(event_px.coords, event_px.values, B, rows[:B, :feat + pix], training, seed ^ 0x1111,
+                                       event_px.value_mode, event_px.noise_std if training else 0.0)
             self.pr_engine.forward(prong_px.coords, prong_px.values, n_prongs, rows[B:, feat:feat + pix], training,
                                    seed ^ 0x2222, prong_px.value_mode, prong_px.noise_std if training else 0.0)
+            main.wait_stream(self._side)
             ev, pr = self.head.forward(rows, tok_row, B, P, n_prongs, training, seed ^ 0x3333)
             if training:
                 self.flat_nbt += self._nbt_inc
@@ -231,12 +237,16 @@ class HipRuntime:
         self._pos_grad.add_(d_rows[:, feat + pix:].sum(0, keepdim=True))
         if self.grad_ready_hook:
             self.grad_ready_hook("head")
-        self.ev_engine.backward(d_rows[:B, :feat + pix])
-        if self.grad_ready_hook:
-            self.grad_ready_hook("event")
+        main = torch.cuda.current_stream(d_rows.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):          # event embedder backward underneath the prong embedder's (see forward)
+            self.ev_engine.backward(d_rows[:B, :feat + pix])
+            if self.grad_ready_hook:
+                self.grad_ready_hook("event")        # the exchange of this segment is ordered after the side stream
         self.pr_engine.backward(d_rows[B:, feat:feat + pix])
         if self.grad_ready_hook:
             self.grad_ready_hook("prong")
+        main.wait_stream(self._side)
 
     def loss(self, ev: Tensor, pr: Tensor, event_targets: Tensor, prong_targets: Tensor):
         """-> (total, event_loss, prong_loss, event_accuracy, prong_accuracy) as 0-d device tensors; total is differentiable."""
