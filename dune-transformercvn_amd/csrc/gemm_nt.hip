@@ -7,6 +7,7 @@
 // One persistent workgroup per CU walks 128-row tiles; each wave owns 32 of the tile's 128 output columns for all rows, so its
 // weight fragments (<= 32 k-steps) live in registers for the whole launch.  The fp32 C tile is exchanged through LDS so that the
 // epilogue touches HBM with 16 B per lane (x, G read / G write) instead of 2-byte accesses in MFMA layout.
+#include <type_traits>
 #include "tcvn_ops.h"
 #include "prof.h"
 
@@ -14,9 +15,12 @@ namespace tcvn {
 
 namespace {
 
-constexpr int ROWS = 128, CLD = 132;            // C tile leading dimension (floats), padded
-constexpr int KS_FWD = 40, KS_FWD_SMALL = 16, KS_DGRAD = 16, KS_POOL = 24;   // k-steps of 16 held in registers per instance
+constexpr int CLD = 132;                        // C tile leading dimension (floats), padded
+// rows per tile: 128 with one workgroup per CU, or 64 with two (their epilogue arithmetic and memory phases then overlap)
 
+constexpr int KS_FWD = 40, KS_FWD_SMALL = 16, KS_DGRAD = 16, KS_DGRAD_SMALL = 8, KS_POOL = 24, KS_POOL_SMALL = 8;   // k-steps of 16 held in registers per instance
+
+template <int ROWS>
 __device__ __forceinline__ void dma_a(char* smem_base, int buf_off, const bf16* __restrict__ A, long lda, int K, int k0, long m0,
                                       long M, const char* __restrict__ zeros, int wave, int lane) {
     const int rsub = lane >> 4, slot = lane & 15;
@@ -32,8 +36,8 @@ __device__ __forceinline__ void dma_a(char* smem_base, int buf_off, const bf16* 
     }
 }
 
-template <int EPI, int MAXKS>
-__global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
+template <int EPI, int MAXKS, int ROWS>
+__global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = ROWS * 256;
     float* Cs = reinterpret_cast<float*>(smem + 2 * TILE);                 // [ROWS][CLD]
@@ -71,33 +75,51 @@ __global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
         csh[j] = (EPI != EPI_FWD && ok) ? g.sh[ncol + j] : 0.f;
         csl[j] = (EPI != EPI_FWD && ok) ? g.sl[ncol + j] : 0.f;
     }
-    double st1[8], st2[8], st3[8];
+    // per-thread running sums: a thread sees at most a few hundred rows per channel, so the two-blocks-per-CU variants keep
+    // them in fp32 (registers); everything across threads and workgroups is reduced in fp64
+    typedef typename std::conditional<ROWS == 64, float, double>::type stat_t;
+    stat_t st1[8], st2[8], st3[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { st1[j] = 0; st2[j] = 0; st3[j] = 0; }
 
     long mt = blockIdx.x;
-    if (mt < mtiles) dma_a(smem, 0, A, g.lda, g.K, 0, mt * ROWS, g.M, zeros, wave, lane);
+    if (mt < mtiles) dma_a<ROWS>(smem, 0, A, g.lda, g.K, 0, mt * ROWS, g.M, zeros, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (; mt < mtiles; mt += gridDim.x) {
-        f32x16 acc[4];
+        f32x16 acc[ROWS / 32];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < ROWS / 32; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        // EPI_DGRAD: the epilogue's x / G rows of this tile are requested now, all at once, so that they travel under the
+        // MFMA phase and next to the A prefetch (a load issued inside the epilogue loop cannot pass the G store of the
+        // previous row group -- same base pointer -- and every row group would pay a full HBM round trip)
+        constexpr bool PREF = EPI == EPI_DGRAD && ROWS == 128;      // with two workgroups per CU the partner hides the latency
+        u16x8 pxv[PREF ? ROWS / 16 : 1], pgv[PREF ? ROWS / 16 : 1];
+        if (PREF && col_ok) {
+#pragma unroll
+            for (int i = 0; i < ROWS / 16; ++i) {
+                const long m = mt * ROWS + c_r0 + 16 * i;
+                if (m < g.M) {
+                    pxv[i] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16*>(g.Xin) + m * g.ldxin + ncol);
+                    pgv[i] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16*>(g.Gout) + m * g.ldgo + ncol);
+                }
+            }
+        }
 #pragma unroll
         for (int kc = 0; kc < MAXKS / 8; ++kc) {
             if (kc < nkc) {
                 // prefetch the next A tile (next k-chunk of this row tile, or the first chunk of the next row tile)
-                if (kc + 1 < nkc) dma_a(smem, (cur ^ 1) * TILE, A, g.lda, g.K, (kc + 1) * 128, mt * ROWS, g.M, zeros, wave, lane);
-                else if (mt + gridDim.x < mtiles) dma_a(smem, (cur ^ 1) * TILE, A, g.lda, g.K, 0, (mt + gridDim.x) * ROWS, g.M, zeros, wave, lane);
+                if (kc + 1 < nkc) dma_a<ROWS>(smem, (cur ^ 1) * TILE, A, g.lda, g.K, (kc + 1) * 128, mt * ROWS, g.M, zeros, wave, lane);
+                else if (mt + gridDim.x < mtiles) dma_a<ROWS>(smem, (cur ^ 1) * TILE, A, g.lda, g.K, 0, (mt + gridDim.x) * ROWS, g.M, zeros, wave, lane);
                 const int ab = cur * TILE;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     if (kc * 8 + ks < ksteps) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
+                        for (int i = 0; i < ROWS / 32; ++i) {
                             const int row = i * 32 + r;
                             const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(smem + ab + row * 256 + (((2 * ks + h) ^ (row & 15)) << 4));
                             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[kc * 8 + ks], acc[i], 0, 0, 0);
@@ -111,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
         }
         // C tile -> LDS (fp32): row = i*32 + (e&3) + 8*(e>>2) + 4*h, column = wave*32 + r
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < ROWS / 32; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) Cs[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wave * 32 + r] = acc[i][e];
         __syncthreads();
@@ -150,9 +172,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
                         for (int t = 0; t < 4; ++t) {
                             if (t < npx) {
                                 const long px = EPI == EPI_DGRAD_POOL ? p00 + (t >> 1) * g.Win + (t & 1) : m;
-                                const u16x8 xv = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16*>(g.Xin) + px * g.ldxin + ncol);
                                 bf16* gp = reinterpret_cast<bf16*>(g.Gout) + px * g.ldgo + ncol;
-                                const u16x8 gv = *reinterpret_cast<const u16x8*>(gp);
+                                u16x8 xv, gv;
+                                if (PREF) { xv = pxv[i]; gv = pgv[i]; }
+                                else {
+                                    xv = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16*>(g.Xin) + px * g.ldxin + ncol);
+                                    gv = *reinterpret_cast<const u16x8*>(gp);
+                                }
                                 u16x8 o;
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) {
@@ -170,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { st1[j] += (double)f1[j]; st2[j] += (double)f2[j]; st3[j] += (double)f3[j]; }
+            for (int j = 0; j < 8; ++j) { st1[j] += (stat_t)f1[j]; st2[j] += (stat_t)f2[j]; st3[j] += (stat_t)f3[j]; }
         }
         __syncthreads();
     }
@@ -179,16 +205,14 @@ __global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
     constexpr int NS = EPI == EPI_FWD ? 2 : 3;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        st1[j] += __shfl_xor(st1[j], 16); st1[j] += __shfl_xor(st1[j], 32);
-        st2[j] += __shfl_xor(st2[j], 16); st2[j] += __shfl_xor(st2[j], 32);
-        if (NS == 3) { st3[j] += __shfl_xor(st3[j], 16); st3[j] += __shfl_xor(st3[j], 32); }
-    }
-    __syncthreads();
-    if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        double d1 = (double)st1[j], d2 = (double)st2[j], d3 = (double)st3[j];
+        d1 += __shfl_xor(d1, 16); d1 += __shfl_xor(d1, 32);
+        d2 += __shfl_xor(d2, 16); d2 += __shfl_xor(d2, 32);
+        if (NS == 3) { d3 += __shfl_xor(d3, 16); d3 += __shfl_xor(d3, 32); }
+        if (j == 0) __syncthreads();                       // red aliases the C tile
+        if (lane < 16) {
             double* p = red + ((wave * 128) + c8 * 8 + j) * 3;
-            p[0] = st1[j]; p[1] = st2[j]; p[2] = st3[j];
+            p[0] = d1; p[1] = d2; p[2] = d3;
         }
     }
     __syncthreads();
@@ -205,6 +229,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
 }  // namespace
 
 static int nt_max_ksteps(int epi) { return epi == EPI_FWD ? KS_FWD : epi == EPI_DGRAD ? KS_DGRAD : KS_POOL; }
+// rows per tile of the instance that serves `a`
+static int nt_rows(const GemmNtArgs& a) {
+    if (a.epi == EPI_DGRAD) return 64;
+    if (a.epi == EPI_DGRAD_POOL) return a.Kp <= KS_POOL_SMALL * 16 ? 64 : 128;
+    return 128;
+}
 bool gemm_nt_ok(const GemmNtArgs& a) {
     if (!a.A || !a.Wfrag || !a.zeros || (a.lda & 7) || (a.K & 7) || a.Kp > nt_max_ksteps(a.epi) * 16 || (a.Kp & 15)) return false;
     if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.Wfrag) & 15)) return false;
@@ -213,29 +243,35 @@ bool gemm_nt_ok(const GemmNtArgs& a) {
            (reinterpret_cast<uintptr_t>(a.Gout) & 15) == 0;
 }
 int gemm_nt_nblk(const GemmNtArgs& a) {
-    const long mt = (a.M + ROWS - 1) / ROWS;
-    return (int)(mt < 256 ? mt : 256);
+    const int rows = nt_rows(a), cap = rows == 64 ? 512 : 256;          // two workgroups per CU for the 64-row tiles
+    const long mt = (a.M + rows - 1) / rows;
+    return (int)(mt < cap ? mt : cap);
 }
 int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
     if (a.M <= 0) return 0;
     if (!gemm_nt_ok(a)) return -2;
     if (a.part != nullptr && a.nblk != gemm_nt_nblk(a)) { fprintf(stderr, "tcvn: gemm_nt nblk mismatch\n"); return -3; }
-    const size_t smem = 2 * ROWS * 256 + (size_t)ROWS * CLD * 4;
+    const int rows = nt_rows(a);
+    const size_t smem = 2 * rows * 256 + (size_t)rows * CLD * 4;
     static bool attr = false;
     if (!attr) {
-        const void* fns[4] = {reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD>),
-                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL>),
-                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD>),
-                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL>)};
+        const void* fns[6] = {reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 128>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD, 64>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD_SMALL, 64>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL, 128>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL_SMALL, 64>)};
         for (const void* f : fns) TCVN_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     ProfScope ps(label, 2.0 * a.M * (double)a.N * a.K, 0.0, st);
     const dim3 grid(gemm_nt_nblk(a), cdiv(a.N, 128));
-    if (a.epi == EPI_FWD && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL>), grid, dim3(256), smem, st, a);
-    else if (a.epi == EPI_FWD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD>), grid, dim3(256), smem, st, a);
-    else if (a.epi == EPI_DGRAD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD>), grid, dim3(256), smem, st, a);
-    else hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL>), grid, dim3(256), smem, st, a);
+    if (a.epi == EPI_FWD && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 128>), grid, dim3(256), smem, st, a);
+    else if (a.epi == EPI_FWD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128>), grid, dim3(256), smem, st, a);
+    else if (a.epi == EPI_DGRAD && a.Kp <= KS_DGRAD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD_SMALL, 64>), grid, dim3(256), smem, st, a);
+    else if (a.epi == EPI_DGRAD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD, 64>), grid, dim3(256), smem, st, a);
+    else if (a.Kp <= KS_POOL_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL_SMALL, 64>), grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL, 128>), grid, dim3(256), smem, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
 }
