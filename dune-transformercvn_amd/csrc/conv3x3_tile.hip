@@ -517,7 +517,7 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
                                        160 * 1024));
         attr = true;
     }
-    ProfScope ps("k_conv3x3_fwd_bf16", 2.0 * a.M * (double)a.N * a.K, 0.0, st);
+    ProfScope ps("k_conv3x3_fwd_bf16", 2.0 * a.M * (double)a.N * a.K, (double)a.M * 2.0 * (a.C + a.N), st);   // read 128 ch, write N ch
     ConvFwdArgs b = a;
     static const int dbg = getenv("TCVN_DBG") ? atoi(getenv("TCVN_DBG")) : 0;
     b.dbg = dbg;
@@ -553,7 +553,7 @@ int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st) {
     }
     if (a.slab == nullptr || (long)nb * (9 * 128 * 32 + 32) * 4 > a.slab_bytes || a.dbias == nullptr) return -3;
     {
-        ProfScope ps("k_conv3x3_wgrad_bf16", 2.0 * a.fa.M * (double)a.e.N * a.fa.K, 0.0, st);
+        ProfScope ps("k_conv3x3_wgrad_bf16", 2.0 * a.fa.M * (double)a.e.N * a.fa.K, (double)a.fa.M * 2.0 * (a.fa.C + 2 * a.e.N), st);   // YA + (G, x) slices
         hipLaunchKernelGGL(k_conv3x3_wgrad_bf16, dim3(nb), dim3(256), wgrad_smem(q), st, a, n_img, ntiles,
                            (nb >= 8 && nb % 8 == 0) ? 1 : 0);
         TCVN_LAUNCH_CHECK();
@@ -585,7 +585,7 @@ int conv3x3_dgrad_tile(const ConvDgradArgs& a, hipStream_t st) {
     const PadGeom q(n_img, a.H, a.W);
     const int ntiles = (int)q.tiles();
     const int nb = tile_grid2(ntiles);
-    ProfScope ps("k_conv3x3_dgrad_bf16", 2.0 * a.M * (double)a.N * 9 * a.e.N, 0.0, st);
+    ProfScope ps("k_conv3x3_dgrad_bf16", 2.0 * a.M * (double)a.N * 9 * a.e.N, (double)a.M * 2.0 * (2 * a.e.N + 2 * a.N), st);   // (G, x) slices in; Y in, DU out
     hipLaunchKernelGGL(k_conv3x3_dgrad_bf16, dim3(nb), dim3(256), dgrad_smem(q), st, a, n_img, ntiles,
                        (nb >= 8 && nb % 8 == 0) ? 1 : 0);
     TCVN_LAUNCH_CHECK();

@@ -175,7 +175,7 @@ int conv_fwd(const ConvFwdArgs& a, hipStream_t st) {
     if (conv3x3_tile_ok(a)) return conv3x3_fwd_tile(a, st);
     char nm[96];
     snprintf(nm, sizeof(nm), "k_conv_fwd<%s,%d,%d>", a.mode == MODE_F32 ? "float" : "bf16", a.amode, a.N <= 32 ? 32 : a.N <= 64 ? 64 : 128);
-    ProfScope ps(nm, 2.0 * a.M * (double)a.N * a.K, 0.0, st);
+    ProfScope ps(nm, 2.0 * a.M * (double)a.N * a.K, (double)a.M * (a.mode == MODE_F32 ? 4.0 : 2.0) * (a.N + (a.amode == A_STEM ? 4.0 * a.C : a.amode == A_3X3 ? (double)a.C : (double)a.K)), st);
     return a.mode == MODE_F32 ? launch_mode<float>(a, st) : launch_mode<bf16>(a, st);
 }
 

@@ -264,7 +264,10 @@ int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
         for (const void* f : fns) TCVN_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    ProfScope ps(label, 2.0 * a.M * (double)a.N * a.K, 0.0, st);
+    // algorithmic HBM bytes: A once; FWD writes N channels; the data-gradient epilogues read x and read+write G (4 pixels per row when pooled)
+    const double px = a.epi == EPI_DGRAD_POOL ? 4.0 : 1.0;
+    const double bytes = (double)a.M * 2.0 * (a.K + (a.epi == EPI_FWD ? (double)a.N : 3.0 * px * a.N));
+    ProfScope ps(label, 2.0 * a.M * (double)a.N * a.K, bytes, st);
     const dim3 grid(gemm_nt_nblk(a), cdiv(a.N, 128));
     if (a.epi == EPI_FWD && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 128>), grid, dim3(256), smem, st, a);
     else if (a.epi == EPI_FWD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128>), grid, dim3(256), smem, st, a);

@@ -140,7 +140,7 @@ int gemm_tn_bf16(const GemmTnArgs& a, const char* label, hipStream_t st) {
     }
     if (a.slab == nullptr || a.Ci <= 0 || a.Ci > a.Li || (long)split * a.Ci * a.ldc * 4 > a.slab_bytes || cdiv(a.ldc, 128) > jt) return -3;
     {
-        ProfScope ps(label, 2.0 * a.M * (double)a.Li * a.Rj, 0.0, st);
+        ProfScope ps(label, 2.0 * a.M * (double)a.Li * a.Rj, (double)a.M * 2.0 * (a.Li + a.Rj), st);
         hipLaunchKernelGGL(k_gemm_tn_bf16, dim3(jt, it, split), dim3(256), 4 * ROWS * 256, st, a, rows);
         TCVN_LAUNCH_CHECK();
     }

@@ -8,6 +8,7 @@ namespace tcvn {
 struct ProfRec { char name[96]; hipEvent_t e0, e1; double flops, bytes; };
 struct Profiler {
     bool enabled = false;
+    char filter[96] = {0};             // when set: only scopes whose label contains it are recorded
     std::vector<ProfRec> recs;
 };
 Profiler& profiler();

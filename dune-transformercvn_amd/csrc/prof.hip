@@ -8,7 +8,7 @@ Profiler& profiler() { static Profiler p; return p; }
 
 ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s) : st(s) {
     Profiler& p = profiler();
-    if (!p.enabled) return;
+    if (!p.enabled || (p.filter[0] && !strstr(name, p.filter))) return;
     ProfRec r;
     strncpy(r.name, name, sizeof(r.name) - 1); r.name[sizeof(r.name) - 1] = 0;
     r.flops = flops; r.bytes = bytes;
@@ -27,6 +27,11 @@ using namespace tcvn;
 
 extern "C" {
 void tcvn_profile_enable(int on) { profiler().enabled = on != 0; }
+void tcvn_profile_filter(const char* substr) {
+    Profiler& p = profiler();
+    p.filter[0] = 0;
+    if (substr) { strncpy(p.filter, substr, sizeof(p.filter) - 1); p.filter[sizeof(p.filter) - 1] = 0; }
+}
 void tcvn_profile_reset(void) {
     for (auto& r : profiler().recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     profiler().recs.clear();

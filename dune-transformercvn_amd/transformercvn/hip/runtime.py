@@ -81,6 +81,7 @@ class HipRuntime:
         self.flat_param = self.flat_grad = self.flat_buf = None
         self._sig = None
         self._grad_views: List[Tensor] = []
+        self.overlap_embedders = True        # event DenseNet on a side stream underneath the prong DenseNet
         self.grad_ready_hook = None          # called as hook(tag) when a gradient segment is final ("head", "event", "prong")
         self.segments: Dict[str, Tuple[int, int]] = {}
 
@@ -213,13 +214,14 @@ class HipRuntime:
             # the two embedders are independent until the token path: the small event DenseNet (B images) runs on a side
             # stream underneath the prong DenseNet (n_prongs images), whose launches alone do not fill the chip in the deep blocks
             main = torch.cuda.current_stream(dev)
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
+            side = self._side if self.overlap_embedders else main
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
                 self.ev_engine.forward(event_px.coords, event_px.values, B, rows[:B, :feat + pix], training, seed ^ 0x1111,
                                        event_px.value_mode, event_px.noise_std if training else 0.0)
             self.pr_engine.forward(prong_px.coords, prong_px.values, n_prongs, rows[B:, feat:feat + pix], training,
                                    seed ^ 0x2222, prong_px.value_mode, prong_px.noise_std if training else 0.0)
-            main.wait_stream(self._side)
+            main.wait_stream(side)
             ev, pr = self.head.forward(rows, tok_row, B, P, n_prongs, training, seed ^ 0x3333)
             if training:
                 self.flat_nbt += self._nbt_inc
@@ -238,15 +240,16 @@ class HipRuntime:
         if self.grad_ready_hook:
             self.grad_ready_hook("head")
         main = torch.cuda.current_stream(d_rows.device)
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):          # event embedder backward underneath the prong embedder's (see forward)
+        side = self._side if self.overlap_embedders else main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):                # event embedder backward underneath the prong embedder's (see forward)
             self.ev_engine.backward(d_rows[:B, :feat + pix])
             if self.grad_ready_hook:
                 self.grad_ready_hook("event")        # the exchange of this segment is ordered after the side stream
         self.pr_engine.backward(d_rows[B:, feat:feat + pix])
         if self.grad_ready_hook:
             self.grad_ready_hook("prong")
-        main.wait_stream(self._side)
+        main.wait_stream(side)
 
     def loss(self, ev: Tensor, pr: Tensor, event_targets: Tensor, prong_targets: Tensor):
         """-> (total, event_loss, prong_loss, event_accuracy, prong_accuracy) as 0-d device tensors; total is differentiable."""

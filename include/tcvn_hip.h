@@ -129,10 +129,12 @@ int tcvn_focal_loss(const float* logits, const int64_t* targets, int rows, int c
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg): when enabled, every convolution launch is bracketed by a HIP event pair on
- * its own stream.  tcvn_profile_get blocks on the record's end event; name is the kernel's template instance, flops the
- * algorithmic 2*M*N*K of that launch.  Off by default; enable only for a separate, untimed step.
+ * its own stream.  tcvn_profile_get blocks on the record's end event; name is the kernel's label, flops the algorithmic
+ * 2*M*N*K of that launch and bytes its algorithmic HBM traffic (operands once, results once).  Off by default; with a
+ * filter set only the matching launches pay for their two events, which is cheap enough for the timed region.
  * --------------------------------------------------------------------------------------------------------------- */
 void tcvn_profile_enable(int on);
+void tcvn_profile_filter(const char* label_substring); /* NULL or "" = every launch; else only matching kernel labels */
 void tcvn_profile_reset(void);
 int tcvn_profile_count(void);
 int tcvn_profile_get(int i, char* name, int name_cap, float* ms, double* flops, double* bytes);
