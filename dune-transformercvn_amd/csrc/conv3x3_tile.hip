@@ -465,6 +465,194 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad_bf16(const ConvDgradAr
     }
 }
 
+// Pipelined variant (concat slice 16-B aligned, 32 channels): the raw (G, x) slice rows of tile t+1 travel by LDS-DMA while
+// tile t is multiplied and its epilogue runs; the epilogue's Y rows are requested one 32-row pass ahead; the per-channel sums
+// stay in registers until the end of the launch.  Barriers inside the pipeline are bare s_barrier + lgkmcnt(0): a
+// __syncthreads() would drain the DMA and the prefetched loads (its fence waits for vmcnt(0)).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradArgs g, int n_img, int ntiles, int swz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const EffSrc& e = g.e;
+    const PadGeom q(n_img, g.H, g.W);
+    const int nr = (q.rows() + 15) & ~15;                       // image rows, whole DMA row groups (16 rows x 64 B = 1 KiB)
+    constexpr int CLD3 = 132;
+    const int o_rg = nr * 64, o_rd = 2 * nr * 64, o_tbl = 3 * nr * 64, o_cs = o_tbl + 2 * nr * 4;     // eff image at 0
+    int* tbl = reinterpret_cast<int*>(smem + o_tbl);            // [2][nr] pixel index per image row (this tile / next tile)
+    float* Cs = reinterpret_cast<float*>(smem + o_cs);          // [32][CLD3] fp32 dA rows of one pass
+    double* red = reinterpret_cast<double*>(smem + o_cs);       // [4][128][3] after the last tile
+    float* tab = reinterpret_cast<float*>(smem + o_cs + 32 * CLD3 * 4);      // sc, sh, sl of norm2 [3][128]; P, Q of the slice [2][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
+    const bf16* __restrict__ G = reinterpret_cast<const bf16*>(e.G);
+    const bf16* __restrict__ D = reinterpret_cast<const bf16*>(e.X);
+    const bf16* __restrict__ Y = reinterpret_cast<const bf16*>(g.Xin);
+    const char* __restrict__ zeros = reinterpret_cast<const char*>(g.zeros);
+    bf16* __restrict__ DU = reinterpret_cast<bf16*>(g.Gout);
+    const int nb = gridDim.x;
+    const int lb = swz ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const bool drop = e.drop_p > 0.f;
+    const uint32_t dkey = drop_key(e.seed, e.stream_id);
+
+    const bf16* __restrict__ Wf = reinterpret_cast<const bf16*>(g.Wfrag) + ((long)wave * 18 * 64 + lane) * 8;
+    bf16x8_t bw[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + i * 512);
+    const int e_c8 = tid & 15, e_r0 = tid >> 4;                 // epilogue role: 8-channel chunk, rows e_r0 + 16*i of a pass
+    if (tid < 128) { tab[tid] = g.sc[tid]; tab[128 + tid] = g.sh[tid]; tab[256 + tid] = g.sl[tid]; }
+    if (tid < 32) { tab[384 + tid] = e.P[tid]; tab[416 + tid] = e.Q[tid]; }
+    const int ec = tid & 3, er0 = tid >> 2;                     // eff role: chunk ec of rows er0 + 64*k
+    float st1[8], st2[8], st3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { st1[j] = 0.f; st2[j] = 0.f; st3[j] = 0.f; }
+
+    auto fill_tbl = [&](int slot, int tile) {
+        for (int rr = tid; rr < nr; rr += 256) tbl[slot * nr + rr] = pix_of(q, tile * TP - q.halo + rr, invWp, invHp);
+    };
+    auto dma_raw = [&](int slot) {                              // both slices, this wave's row groups; padding rows <- zeros
+        const int rsub = lane >> 2, chunk = lane & 3;
+        for (int rg = wave; rg * 16 < nr; rg += 4) {
+            const int m = tbl[slot * nr + rg * 16 + rsub];
+            const char* sg = m >= 0 ? reinterpret_cast<const char*>(G + (long)m * e.ldg + e.c_off) + chunk * 16 : zeros + chunk * 16;
+            const char* sd = m >= 0 ? reinterpret_cast<const char*>(D + (long)m * e.ldx + e.c_off) + chunk * 16 : zeros + chunk * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sg,
+                                             (__attribute__((address_space(3))) void*)(smem + o_rg + rg * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd,
+                                             (__attribute__((address_space(3))) void*)(smem + o_rd + rg * 1024), 16, 0, 0);
+        }
+    };
+    auto load_y = [&](int slot, int pass, u16x8 (&yv)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = tbl[slot * nr + q.halo + pass * 32 + e_r0 + 16 * i];
+            yv[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (m >= 0) yv[i] = *reinterpret_cast<const u16x8*>(Y + (long)m * g.ldxin + e_c8 * 8);
+        }
+    };
+
+    int cur = 0;
+    if (lb < ntiles) fill_tbl(0, lb);
+    __syncthreads();
+    if (lb < ntiles) dma_raw(0);
+    for (int t = lb; t < ntiles; t += nb, cur ^= 1) {
+        if (t + nb < ntiles) fill_tbl(cur ^ 1, t + nb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of tile t's raw rows has landed
+        __syncthreads();                                         // ... and everybody else's; next table visible
+        // eff image: 16-B chunk ec of row rr at off64(rr, ec);  eff = (G + P*x + Q) * dropout, exactly 0 on padding rows
+        float cP[8], cQ[8];
+        {
+            const float4 p0 = *reinterpret_cast<const float4*>(tab + 384 + ec * 8), p1 = *reinterpret_cast<const float4*>(tab + 388 + ec * 8);
+            const float4 q0 = *reinterpret_cast<const float4*>(tab + 416 + ec * 8), q1 = *reinterpret_cast<const float4*>(tab + 420 + ec * 8);
+            cP[0] = p0.x; cP[1] = p0.y; cP[2] = p0.z; cP[3] = p0.w; cP[4] = p1.x; cP[5] = p1.y; cP[6] = p1.z; cP[7] = p1.w;
+            cQ[0] = q0.x; cQ[1] = q0.y; cQ[2] = q0.z; cQ[3] = q0.w; cQ[4] = q1.x; cQ[5] = q1.y; cQ[6] = q1.z; cQ[7] = q1.w;
+        }
+        for (int rr = er0; rr < nr; rr += 64) {
+            const int m = tbl[cur * nr + rr];
+            u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (m >= 0) {
+                const u16x8 gv = *reinterpret_cast<const u16x8*>(smem + o_rg + rr * 64 + ec * 16);
+                const u16x8 xv = *reinterpret_cast<const u16x8*>(smem + o_rd + rr * 64 + ec * 16);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
+                    if (drop) v *= drop_pick(drop_bits(dkey, m, ec * 8 + j, e.N), m, e.drop_p);
+                    o[j] = f2bf(v);
+                }
+            }
+            *reinterpret_cast<u16x8*>(smem + off64(rr, ec)) = o;
+        }
+        __syncthreads();                                         // image complete, raw buffers free again
+        if (t + nb < ntiles) dma_raw(cur ^ 1);                   // next tile's slices travel under the MFMAs + epilogue
+        u16x8 ya[2], yb[2];
+        load_y(cur, 0, ya);
+
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int base = q.halo - ((tap / 3 - 1) * q.Wp + (tap % 3 - 1)) + r;      // source position = p - shift(tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int lr = base + mt * 32;
+                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(smem + off64(lr, 2 * ks + h));
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[tap * 2 + ks], acc[mt], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue, four passes of 32 rows through the fp32 C tile: u = sc*y + sh ; dU = dA * prelu'(u) ; DU = sc*dU ;
+        // sums (dU, dU*y, dA*min(u,0)) per channel
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            u16x8 (&yc)[2] = (pass & 1) ? yb : ya;
+            u16x8 (&yn)[2] = (pass & 1) ? ya : yb;
+            if (pass < 3) load_y(cur, pass + 1, yn);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Cs[((k & 3) + 8 * (k >> 2) + 4 * h) * CLD3 + wave * 32 + r] = acc[pass][k];
+            lds_barrier();
+            float esc[8], esh[8], esl[8];
+#pragma unroll
+            for (int j4 = 0; j4 < 2; ++j4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(tab + e_c8 * 8 + j4 * 4);
+                const float4 b4 = *reinterpret_cast<const float4*>(tab + 128 + e_c8 * 8 + j4 * 4);
+                const float4 c4 = *reinterpret_cast<const float4*>(tab + 256 + e_c8 * 8 + j4 * 4);
+                esc[j4 * 4] = a4.x; esc[j4 * 4 + 1] = a4.y; esc[j4 * 4 + 2] = a4.z; esc[j4 * 4 + 3] = a4.w;
+                esh[j4 * 4] = b4.x; esh[j4 * 4 + 1] = b4.y; esh[j4 * 4 + 2] = b4.z; esh[j4 * 4 + 3] = b4.w;
+                esl[j4 * 4] = c4.x; esl[j4 * 4 + 1] = c4.y; esl[j4 * 4 + 2] = c4.z; esl[j4 * 4 + 3] = c4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rr = e_r0 + 16 * i;
+                const int m = tbl[cur * nr + q.halo + pass * 32 + rr];
+                if (m >= 0) {
+                    const float4 ca = *reinterpret_cast<const float4*>(Cs + rr * CLD3 + e_c8 * 8);
+                    const float4 cc = *reinterpret_cast<const float4*>(Cs + rr * CLD3 + e_c8 * 8 + 4);
+                    const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cc.x, cc.y, cc.z, cc.w};
+                    u16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = bf2f(yc[i][j]);
+                        const float u = fmaf(y, esc[j], esh[j]);
+                        const float du = u > 0.f ? cv[j] : esl[j] * cv[j];
+                        st1[j] += du; st2[j] += du * y; st3[j] += u > 0.f ? 0.f : cv[j] * u;
+                        o[j] = f2bf(esc[j] * du);
+                    }
+                    *reinterpret_cast<u16x8*>(DU + (long)m * g.ldgo + e_c8 * 8) = o;
+                }
+            }
+            lds_barrier();
+        }
+    }
+    // reduce the 16 row groups: 4 per wave by shuffles (lane bits 4, 5), then across waves through LDS
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double d1 = (double)st1[j], d2 = (double)st2[j], d3 = (double)st3[j];
+        d1 += __shfl_xor(d1, 16); d1 += __shfl_xor(d1, 32);
+        d2 += __shfl_xor(d2, 16); d2 += __shfl_xor(d2, 32);
+        d3 += __shfl_xor(d3, 16); d3 += __shfl_xor(d3, 32);
+        if (lane < 16) {
+            double* p = red + ((wave * 128) + e_c8 * 8 + j) * 3;
+            p[0] = d1; p[1] = d2; p[2] = d3;
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        double a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += red[(w * 128 + tid) * 3]; b += red[(w * 128 + tid) * 3 + 1]; c += red[(w * 128 + tid) * 3 + 2]; }
+        double* p = g.part + ((long)blockIdx.x * g.N + tid) * 3;
+        p[0] = a; p[1] = b; p[2] = c;
+    }
+}
+
+size_t dgrad2_smem(const PadGeom& q) { const size_t nr = (q.rows() + 15) & ~15; return 3 * nr * 64 + 2 * nr * 4 + 32 * 132 * 4 + 448 * 4; }
 size_t dgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return r4 * 68 + 128 * 24 + 64 * 132 * 4; }
 int tile_grid2(long ntiles) {           // two workgroups per CU
     if (ntiles >= 512) return 512;
@@ -586,6 +774,18 @@ int conv3x3_dgrad_tile(const ConvDgradArgs& a, hipStream_t st) {
     const int ntiles = (int)q.tiles();
     const int nb = tile_grid2(ntiles);
     ProfScope ps("k_conv3x3_dgrad_bf16", 2.0 * a.M * (double)a.N * 9 * a.e.N, (double)a.M * 2.0 * (2 * a.e.N + 2 * a.N), st);   // (G, x) slices in; Y in, DU out
+    // pipelined variant: needs the concat slice 16-B aligned for the LDS-DMA and all 32 channels present
+    if (a.zeros != nullptr && a.e.N == 32 && (a.e.c_off & 7) == 0 && dgrad2_smem(q) <= 80 * 1024 &&
+        (reinterpret_cast<uintptr_t>(a.e.G) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.e.X) & 15) == 0) {
+        static bool attr = false;
+        if (!attr) {
+            TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_dgrad2_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(k_conv3x3_dgrad2_bf16, dim3(nb), dim3(256), dgrad2_smem(q), st, a, n_img, ntiles, (nb >= 8 && nb % 8 == 0) ? 1 : 0);
+        TCVN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_conv3x3_dgrad_bf16, dim3(nb), dim3(256), dgrad_smem(q), st, a, n_img, ntiles,
                        (nb >= 8 && nb % 8 == 0) ? 1 : 0);
     TCVN_LAUNCH_CHECK();

@@ -209,7 +209,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 d.mode = mode; d.dmode = DG_3X3; d.e = e2; d.M = (int)M; d.N = mid; d.Kp = et.Kp; d.H = bg.H; d.W = bg.W;
                 d.Wt = ws + L.wk + et.off; d.Xin = Y; d.ldxin = mid; d.sc = sc_of(ls.n2); d.sh = sh_of(ls.n2); d.sl = data[ls.a2];
                 d.Gout = DU; d.ldgo = mid; d.accumulate = 0; d.part = part;
-                d.Wfrag = wk_frag(ws, L, ls.w2, 1);
+                d.Wfrag = wk_frag(ws, L, ls.w2, 1); d.zeros = ws + L.zeros;
                 d.nblk = conv_dgrad_nblk(d);
                 if ((rc = conv_dgrad(d, st))) return rc;
                 if ((rc = bwd_link(ls.n2, d.nblk, reinterpret_cast<const double*>(ws + L.bstatY[bi][l]), M, PY, QY, 0, ls.a2))) return rc;

@@ -119,6 +119,7 @@ struct ConvDgradArgs {
     void* Gout; long ldgo; int accumulate;
     double* part; int nblk;        // [nblk][N][3]
     const void* Wfrag;             // optional: Wt in MFMA fragment order (bf16 padded-tile 3x3 kernel)
+    const void* zeros;             // optional: >= 64 B of zeros (LDS-DMA source of padding rows)
 };
 int conv_dgrad(const ConvDgradArgs& a, hipStream_t st);
 int conv_dgrad_nblk(const ConvDgradArgs& a);      // grid.x (rows of `part`) conv_dgrad will use (<= 512)
