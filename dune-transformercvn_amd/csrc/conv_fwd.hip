@@ -166,12 +166,16 @@ int conv_fwd_grid(int M) {
     return mtiles < 512 ? mtiles : 512;
 }
 
-int conv_fwd_nblk(const ConvFwdArgs& a) { return conv3x3_tile_ok(a) ? conv3x3_tile_nblk(a) : conv_fwd_grid(a.M); }
+int conv_fwd_nblk(const ConvFwdArgs& a) {
+    if (stem_fwd_ok(a)) return stem_fwd_nblk(a);
+    return conv3x3_tile_ok(a) ? conv3x3_tile_nblk(a) : conv_fwd_grid(a.M);
+}
 
 int conv_fwd(const ConvFwdArgs& a, hipStream_t st) {
     if (a.M <= 0) return 0;
     if (a.Kp % BK != 0 || a.Kp < a.K) { fprintf(stderr, "tcvn: conv_fwd bad Kp=%d K=%d\n", a.Kp, a.K); return -2; }
     if (a.part != nullptr && a.nblk != conv_fwd_nblk(a)) { fprintf(stderr, "tcvn: conv_fwd nblk mismatch\n"); return -3; }
+    if (stem_fwd_ok(a)) return stem_fwd_bf16(a, st);
     if (conv3x3_tile_ok(a)) return conv3x3_fwd_tile(a, st);
     char nm[96];
     snprintf(nm, sizeof(nm), "k_conv_fwd<%s,%d,%d>", a.mode == MODE_F32 ? "float" : "bf16", a.amode, a.N <= 32 ? 32 : a.N <= 64 ? 64 : 128);

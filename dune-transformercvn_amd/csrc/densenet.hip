@@ -354,7 +354,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         a.mode = mode; a.amode = A_STEM; a.A = ws + L.img; a.lda = cfg.in_ch; a.M = (int)M0; a.N = cfg.init_ch;
         a.K = 49 * cfg.in_ch; a.Kp = e.Kp; a.C = cfg.in_ch; a.H = Hc; a.W = Wc; a.Hin = cfg.H; a.Win = cfg.W;
         a.Wk = ws + L.wk + e.off; a.bias = data[s_b0]; a.Out = ws + L.c0; a.ldo = cfg.init_ch; a.n_off = 0;
-        a.part = train ? part : nullptr; a.nblk = conv_fwd_grid((int)M0);
+        a.part = train ? part : nullptr; a.nblk = conv_fwd_nblk(a);
         if ((rc = conv_fwd(a, st))) return rc;
         if ((rc = link(n0, part, a.nblk, cfg.init_ch, 0, cfg.init_ch, reinterpret_cast<double*>(ws + L.bstat0), M0))) return rc;
     }

@@ -139,6 +139,143 @@ __global__ __launch_bounds__(256) void k_stem_wgrad_sparse(const StemWgradArgs a
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv0 forward (7x7, stride 2, pad 3, 3 -> 64 channels; reference layers/dense_net.py:112-116) as an implicit GEMM:
+// one workgroup = 8 x 16 output pixels of one map; its 21 x 37 input patch is staged in LDS as NHWC4 (8 B per pixel, the
+// 4th channel zero) so that the 8 contraction elements of an MFMA lane -- 2 neighbouring pixels of one kernel row -- are
+// one aligned ds_read_b128.  Contraction order k' = ky*32 + kx*4 + c (kx = 7 and c = 3 carry zero weights): 14 k-steps
+// of 16.  Each wave owns 2 output rows x 16 columns x 64 channels; the weights (28 fragments) stay in registers.
+// The tile leaves through a bf16 C tile in LDS so that every lane stores 16 B of the NHWC output row.
+// Algorithmic HBM bytes per map: 400*280*3*2 read + 200*140*64*2 written (the write dominates: 1.03 GB for 288 maps).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int ST_TH = 8, ST_TW = 16;                        // output tile
+constexpr int ST_PR = 2 * ST_TH + 5, ST_PW = 40;            // patch rows, patch pitch in pixels (37 used)
+constexpr int ST_CP = 72;                                   // C tile pitch in bf16 (64 + 8: lane halves on different banks)
+
+__global__ __launch_bounds__(256, 2) void k_stem_fwd_bf16(const ConvFwdArgs g, int n_img, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) unsigned short patch[2][ST_PR * ST_PW * 4];
+    __shared__ __attribute__((aligned(16))) unsigned short ctile[ST_TH * ST_TW * ST_CP];
+    __shared__ double red[4][64][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const bf16* __restrict__ img = reinterpret_cast<const bf16*>(g.A);
+    const bf16* __restrict__ Wk = reinterpret_cast<const bf16*>(g.Wk);          // [64][Kp], k = (ky*7 + kx)*3 + c
+    bf16* __restrict__ Out = reinterpret_cast<bf16*>(g.Out);
+    const int Hin = g.Hin, Win = g.Win, Ho = g.H, Wo = g.W;
+    const long ntiles = (long)n_img * tiles_x * tiles_y;
+
+    // weight fragments: lane (r, h) of n-tile nt holds k' = 16 s + 8 h + i for output channel nt*32 + r
+    bf16x8_t bw[2][14];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            u16x8 w;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kp = 16 * s + 8 * h + i, ky = kp >> 5, kx = (kp & 31) >> 2, c = kp & 3;
+                w[i] = (kx < 7 && c < 3) ? Wk[(long)(nt * 32 + r) * g.Kp + (ky * 7 + kx) * 3 + c] : (bf16)0;
+            }
+            bw[nt][s] = __builtin_bit_cast(bf16x8_t, w);
+        }
+    const float bias0 = g.bias[r], bias1 = g.bias[32 + r];
+    for (int i = tid; i < 2 * ST_PR * ST_PW * 4; i += 256) (&patch[0][0])[i] = 0;      // 4th channel + pitch padding stay zero
+    double s1[2] = {0, 0}, s2[2] = {0, 0};
+
+    // patch staging: element e of patch row pr is input (iy0 + pr, ix0 + e/3, channel e%3); 21 x 111 elements, <= 10 per thread
+    constexpr int NE = ST_PR * 37 * 3, PER = (NE + 255) / 256;
+    auto load_patch = [&](long tile, unsigned short (&v)[PER]) {
+        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+        const long n = tile / ((long)tiles_x * tiles_y);
+        const int iy0 = 2 * ty * ST_TH - 3, ix0 = 2 * tx * ST_TW - 3;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + 256 * k;
+            const int pr = i / 111, e = i - pr * 111, px = e / 3, c = e - px * 3;
+            const int iy = iy0 + pr, ix = ix0 + px;
+            v[k] = 0;
+            if (i < NE && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) v[k] = img[((n * Hin + iy) * Win + ix) * 3 + c];
+        }
+    };
+    auto store_patch = [&](int buf, const unsigned short (&v)[PER]) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + 256 * k;
+            const int pr = i / 111, e = i - pr * 111, px = e / 3, c = e - px * 3;
+            if (i < NE) patch[buf][(pr * ST_PW + px) * 4 + c] = v[k];
+        }
+    };
+
+    unsigned short pv[PER];
+    long tile = blockIdx.x;
+    __syncthreads();
+    if (tile < ntiles) { load_patch(tile, pv); store_patch(0, pv); }
+    __syncthreads();
+    int cur = 0;
+    const int oy_l = 2 * wave + (r >> 4), ox_l = r & 15;          // this lane's pixel of the wave's 32-pixel M tile
+    for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+        const bool more = tile + gridDim.x < ntiles;
+        if (more) load_patch(tile + gridDim.x, pv);                // next patch travels under the MFMAs
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[nt][k] = 0.f;
+        const unsigned short* pb = &patch[cur][0];
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int gq = 2 * s + h, ky = gq >> 2, q4 = gq & 3;
+            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(pb + ((2 * oy_l + ky) * ST_PW + 2 * ox_l + 2 * q4) * 4);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[0][s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[1][s], acc[1], 0, 0, 0);
+        }
+        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+        const long n = tile / ((long)tiles_x * tiles_y);
+        const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+        // C layout: pixel row of the M tile = (k&3) + 8*(k>>2) + 4*h, channel = nt*32 + r
+        float f1[2] = {0, 0}, f2[2] = {0, 0};
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int pr = (k & 3) + 8 * (k >> 2) + 4 * h;         // 0..31 inside the wave's two rows
+                const int py = 2 * wave + (pr >> 4), px = pr & 15;
+                const bf16 o = f2bf(acc[nt][k] + (nt ? bias1 : bias0));
+                ctile[(py * ST_TW + px) * ST_CP + nt * 32 + r] = o;
+                if (oy0 + py < Ho && ox0 + px < Wo) { const float x = bf2f(o); f1[nt] += x; f2[nt] += x * x; }
+            }
+        s1[0] += (double)f1[0]; s2[0] += (double)f2[0]; s1[1] += (double)f1[1]; s2[1] += (double)f2[1];
+        if (more) store_patch(cur ^ 1, pv);
+        __syncthreads();
+        // 128 pixels x 128 B: 4 chunks of 16 B per thread
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + 256 * k, p = idx >> 3, c8 = idx & 7;
+            const int py = p >> 4, px = p & 15;
+            if (oy0 + py < Ho && ox0 + px < Wo)
+                *reinterpret_cast<u16x8*>(Out + ((n * Ho + oy0 + py) * (long)Wo + ox0 + px) * g.ldo + c8 * 8) =
+                    *reinterpret_cast<const u16x8*>(&ctile[p * ST_CP + c8 * 8]);
+        }
+        __syncthreads();
+    }
+    if (g.part != nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            double a = s1[nt], b = s2[nt];
+            a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+            if (lane < 32) { red[wave][nt * 32 + lane][0] = a; red[wave][nt * 32 + lane][1] = b; }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double a = 0, b = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += red[w][tid][0]; b += red[w][tid][1]; }
+            g.part[((long)blockIdx.x * 64 + tid) * 2] = a;
+            g.part[((long)blockIdx.x * 64 + tid) * 2 + 1] = b;
+        }
+    }
+}
 }  // namespace
 
 int pool0_bwd_vec_grid(int n_img, int Hin, int Win) {
@@ -166,6 +303,24 @@ int stem_wgrad_sparse(const StemWgradArgs& a, float* dWk, hipStream_t st) {
         TCVN_LAUNCH_CHECK();
     }
     return slab_reduce(a.slab, nb, (long)a.e.N * a.Kp, dWk, st);
+}
+
+
+bool stem_fwd_ok(const ConvFwdArgs& a) {
+    return conv3x3_tile_enabled() && a.mode == MODE_BF16 && a.amode == A_STEM && a.C == 3 && a.N == 64 && a.K == 147 && a.Kp >= 147 &&
+           a.ldo == 64 && a.n_off == 0 && a.Hin == 2 * a.H && a.Win == 2 * a.W && a.M % (a.H * a.W) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.Out) & 15) == 0;
+}
+int stem_fwd_nblk(const ConvFwdArgs& a) {
+    const long nt = (long)(a.M / (a.H * a.W)) * cdiv(a.W, ST_TW) * cdiv(a.H, ST_TH);
+    return (int)(nt < 512 ? nt : 512);
+}
+int stem_fwd_bf16(const ConvFwdArgs& a, hipStream_t st) {
+    const int n_img = a.M / (a.H * a.W);
+    ProfScope ps("k_stem_fwd_bf16", 2.0 * a.M * (double)a.N * a.K, (double)a.M * 2.0 * (a.N + 4.0 * a.C), st);
+    hipLaunchKernelGGL(k_stem_fwd_bf16, dim3(stem_fwd_nblk(a)), dim3(256), 0, st, a, n_img, cdiv(a.W, ST_TW), cdiv(a.H, ST_TH));
+    TCVN_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace tcvn

@@ -212,6 +212,10 @@ struct StemWgradArgs {
     int Hc, Wc, Kp; float* slab; long slab_bytes;
 };
 int stem_wgrad_sparse(const StemWgradArgs& a, float* dWk, hipStream_t st);
+// conv0 forward on an NHWC4 LDS patch (bf16, 3 -> 64 channels, 7x7 / 2)
+bool stem_fwd_ok(const ConvFwdArgs& a);
+int stem_fwd_nblk(const ConvFwdArgs& a);
+int stem_fwd_bf16(const ConvFwdArgs& a, hipStream_t st);
 
 // kernel-layout fp32 weight gradients -> reference OIHW gradients (accumulate)
 struct UnpackDesc { const float* src; float* dst; int N, Cin, taps, Kp; int nfast; };   // nfast: src is [k][32]
