@@ -177,12 +177,20 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const AddLnBwdArgs a) {
     }
 }
 // column reductions for LayerNorm affine grads: dgamma[d] += sum_t dY*xhat ; dbeta[d] += sum_t dY
-__global__ void k_ln_param_grads(const float* dY, const float* XH, int T, int D, float* dgamma, float* dbeta) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
+__global__ __launch_bounds__(256) void k_ln_param_grads(const float* dY, const float* XH, int T, int D, float* dgamma, float* dbeta) {
+    __shared__ double sa[16][17], sb[16][17];                // 16 columns x 16 row lanes per workgroup
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, d = blockIdx.x * 16 + cl;
     double a = 0, b = 0;
-    for (int t = 0; t < T; ++t) { const float g = dY[(long)t * D + d]; a += (double)g * XH[(long)t * D + d]; b += g; }
-    dgamma[d] += (float)a; dbeta[d] += (float)b;
+    if (d < D)
+        for (int t = rl; t < T; t += 16) { const float g = dY[(long)t * D + d]; a += (double)g * XH[(long)t * D + d]; b += g; }
+    sa[rl][cl] = a; sb[rl][cl] = b;
+    __syncthreads();
+    if (threadIdx.x < 16 && d < D) {
+        double x = 0, y = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { x += sa[i][cl]; y += sb[i][cl]; }
+        dgamma[d] += (float)x; dbeta[d] += (float)y;
+    }
 }
 
 __global__ void k_act_fwd(const float* X, float* Y, long n, int gelu, float drop_p, uint64_t seed, uint32_t stream_id) {
@@ -308,7 +316,7 @@ int add_ln_bwd(const AddLnBwdArgs& a, hipStream_t st) {
     if (a.D > 512) return -2;
     hipLaunchKernelGGL(k_add_ln_bwd, dim3(cdiv(a.T, 4)), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ln_param_grads, dim3(cdiv(a.D, 64)), dim3(64), 0, st, a.dY, a.XH, a.T, a.D, a.dgamma, a.dbeta);
+    hipLaunchKernelGGL(k_ln_param_grads, dim3(cdiv(a.D, 16)), dim3(256), 0, st, a.dY, a.XH, a.T, a.D, a.dgamma, a.dbeta);
     TCVN_LAUNCH_CHECK(); return 0;
 }
 int act_fwd(const float* X, float* Y, long n, int gelu, float drop_p, uint64_t seed, uint32_t sid, hipStream_t st) {

@@ -34,20 +34,20 @@ __global__ __launch_bounds__(256) void k_sgemm(const SgemmArgs a) {
 
 // ---- BatchNorm1d (+PReLU/ReLU, +Dropout) over R rows -------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rows_bn_fwd(const RowsBnArgs a) {
-    __shared__ double red[4][64][2];
-    __shared__ float s_mean[64], s_rstd[64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double red[16][16][2];
+    __shared__ float s_mean[16], s_rstd[16];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;      // 16 columns x 16 row lanes per workgroup
+    const int c = blockIdx.x * 16 + cl;
     const bool ok = c < a.C;
     if (a.train) {
         double s1 = 0, s2 = 0;
         if (ok)
-            for (int r = rg; r < a.R; r += 4) { const double v = a.X[(long)r * a.ldx + c]; s1 += v; s2 += v * v; }
+            for (int r = rg; r < a.R; r += 16) { const double v = a.X[(long)r * a.ldx + c]; s1 += v; s2 += v * v; }
         red[rg][cl][0] = s1; red[rg][cl][1] = s2;
         __syncthreads();
         if (rg == 0 && ok) {
             double x = 0, y = 0;
-            for (int g = 0; g < 4; ++g) { x += red[g][cl][0]; y += red[g][cl][1]; }
+            for (int g = 0; g < 16; ++g) { x += red[g][cl][0]; y += red[g][cl][1]; }
             const double mean = x / a.R;
             double var = y / a.R - mean * mean;
             if (var < 0) var = 0;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_rows_bn_fwd(const RowsBnArgs a) {
     const float mean = s_mean[cl], rstd = s_rstd[cl];
     const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
     const float sl = a.slope ? a.slope[c] : 0.f;
-    for (int r = rg; r < a.R; r += 4) {
+    for (int r = rg; r < a.R; r += 16) {
         const float u = (a.X[(long)r * a.ldx + c] - mean) * rstd * g + b;
         float z = prelu(u, sl);
         if (a.train && a.drop_p > 0.f) z *= drop_scale(a.drop_p, a.seed, a.stream_id, (uint64_t)r * a.C + c);
@@ -79,17 +79,17 @@ __global__ __launch_bounds__(256) void k_rows_bn_fwd(const RowsBnArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_rows_bn_bwd(const RowsBnBwdArgs a) {
-    __shared__ double red[4][64][3];
-    __shared__ float s_db[64], s_dg[64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double red[16][16][3];
+    __shared__ float s_db[16], s_dg[16];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;      // 16 columns x 16 row lanes per workgroup
+    const int c = blockIdx.x * 16 + cl;
     const bool ok = c < a.C;
     const float mean = ok ? a.save_mean[c] : 0.f, rstd = ok ? a.save_rstd[c] : 0.f;
     const float g = (ok && a.gamma) ? a.gamma[c] : 1.f, b = (ok && a.beta) ? a.beta[c] : 0.f;
     const float sl = (ok && a.slope) ? a.slope[c] : 0.f;
     double s1 = 0, s2 = 0, s3 = 0;
     if (ok)
-        for (int r = rg; r < a.R; r += 4) {
+        for (int r = rg; r < a.R; r += 16) {
             const float xh = (a.X[(long)r * a.ldx + c] - mean) * rstd;
             const float u = xh * g + b;
             float dz = a.dY[(long)r * a.lddy + c];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_rows_bn_bwd(const RowsBnBwdArgs a) {
     __syncthreads();
     if (rg == 0 && ok) {
         double x = 0, y = 0, z = 0;
-        for (int q = 0; q < 4; ++q) { x += red[q][cl][0]; y += red[q][cl][1]; z += red[q][cl][2]; }
+        for (int q = 0; q < 16; ++q) { x += red[q][cl][0]; y += red[q][cl][1]; z += red[q][cl][2]; }
         s_db[cl] = (float)x; s_dg[cl] = (float)y;
         if (a.dbeta) a.dbeta[c] += (float)x;
         if (a.dgamma) a.dgamma[c] += (float)y;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_rows_bn_bwd(const RowsBnBwdArgs a) {
     __syncthreads();
     if (!ok || a.dX == nullptr) return;
     const float db = s_db[cl] / a.R, dg = s_dg[cl] / a.R;
-    for (int r = rg; r < a.R; r += 4) {
+    for (int r = rg; r < a.R; r += 16) {
         const float xh = (a.X[(long)r * a.ldx + c] - mean) * rstd;
         const float u = xh * g + b;
         float dz = a.dY[(long)r * a.lddy + c];
@@ -120,12 +120,20 @@ __global__ __launch_bounds__(256) void k_rows_bn_bwd(const RowsBnBwdArgs a) {
     }
 }
 
-__global__ void k_colsum_acc(const float* dY, long lddy, int R, int N, float* db) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+__global__ __launch_bounds__(256) void k_colsum_acc(const float* dY, long lddy, int R, int N, float* db) {
+    __shared__ double sa[16][17];                            // 16 columns x 16 row lanes per workgroup
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, n = blockIdx.x * 16 + cl;
     double s = 0;
-    for (int r = 0; r < R; ++r) s += dY[(long)r * lddy + n];
-    db[n] += (float)s;
+    if (n < N)
+        for (int r = rl; r < R; r += 16) s += dY[(long)r * lddy + n];
+    sa[rl][cl] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && n < N) {
+        double x = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x += sa[i][cl];
+        db[n] += (float)x;
+    }
 }
 
 }  // namespace
@@ -136,7 +144,7 @@ int linear_bwd_dw(const float* dY, long lddy, const float* X, long ldx, float* d
     int rc = sgemm(a, st);
     if (rc) return rc;
     if (db) {
-        hipLaunchKernelGGL(k_colsum_acc, dim3(cdiv(N, 64)), dim3(64), 0, st, dY, lddy, R, N, db);
+        hipLaunchKernelGGL(k_colsum_acc, dim3(cdiv(N, 16)), dim3(256), 0, st, dY, lddy, R, N, db);
         TCVN_LAUNCH_CHECK();
     }
     return 0;
@@ -150,13 +158,13 @@ int sgemm(const SgemmArgs& a, hipStream_t st) {
 }
 int rows_bn_fwd(const RowsBnArgs& a, hipStream_t st) {
     if (a.R <= 0) return 0;
-    hipLaunchKernelGGL(k_rows_bn_fwd, dim3(cdiv(a.C, 64)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_rows_bn_fwd, dim3(cdiv(a.C, 16)), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
 }
 int rows_bn_bwd(const RowsBnBwdArgs& a, hipStream_t st) {
     if (a.R <= 0) return 0;
-    hipLaunchKernelGGL(k_rows_bn_bwd, dim3(cdiv(a.C, 64)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_rows_bn_bwd, dim3(cdiv(a.C, 16)), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
 }
