@@ -72,6 +72,17 @@ def cpu_baseline(threads):
             "sample": "oracle fp32 fwd+loss+bwd, B=2 x 4 prongs (10 maps), 2-layer encoder, median of 3 steps after 1 warm-up"}
 
 
+def pmc_traffic(label):
+    """HBM bytes per launch of `label` from the committed rocprofv3 PMC passes of this command (tools/pmc_traffic.py), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(label)
+        return round(rec["traffic_bytes_per_launch"]) if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,7 +208,7 @@ def main():
             ach, peak, unit = fl / ms / 1e9, PEAK[args.precision], "TFLOP/s"
         roof = {"bound": "hbm" if hbm_bound else "mfma", "kernel": top, "launches_per_step": n // max(args.steps, 1),
                 "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n, "bytes_per_launch": by / n,
-                "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
+                "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": pmc_traffic(top),
                 "measured": f"HIP events on the launch stream, all {n} launches of the {args.steps} timed steps",
                 "survey_ms_per_step": round(sum(a[1] for a in agg.values()), 2)}
     if world > 1:

@@ -73,8 +73,9 @@ int tcvn_densenet_forward(tcvn_densenet* p, int n_img, const int32_t* coords, co
 int tcvn_densenet_backward(tcvn_densenet* p, int n_img, const float* d_out, int64_t d_out_ld, void* workspace,
                            int64_t workspace_bytes, void* stream);
 
-/* Debug/validation taps into the workspace of the last forward: name in {"conv0","pool0","dense<i>","bottleneck<b>.<l>",
- * "condense"}; returns element offset (bytes) and logical NHWC shape + channel stride. */
+/* Debug/validation taps into the workspace of the last forward: name in {"conv0","dense<b>","bottleneck<b>.<l>","condense"},
+ * in bf16 mode also the materialised operands "xa<b>.<l>" / "ya<b>.<l>" and the raw regions "raw:wk","raw:tabs","raw:bstat<b>";
+ * returns the byte offset into the workspace and the logical NHWC shape + channel stride + element size. */
 int tcvn_densenet_tap(const tcvn_densenet* p, int n_img, const char* name, int64_t* byte_off, int* n, int* h, int* w,
                       int* c, int* ld, int* elem_bytes);
 
