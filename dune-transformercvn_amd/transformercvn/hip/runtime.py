@@ -84,6 +84,7 @@ class HipRuntime:
         self.overlap_embedders = True        # event DenseNet on a side stream underneath the prong DenseNet
         self.grad_ready_hook = None          # called as hook(tag) when a gradient segment is final ("head", "event", "prong")
         self.segments: Dict[str, Tuple[int, int]] = {}
+        self.offsets: Dict[str, Tuple[int, int]] = {}
 
     # ---------------------------------------------------------------------------------------------------------------
     # flat arenas
@@ -128,6 +129,7 @@ class HipRuntime:
             b.data = flat_b[off:off + k].view(b.shape)
             off += k
         self.flat_param, self.flat_grad, self.flat_buf = flat_p, flat_g, flat_b
+        self.offsets = offsets                        # name (relative to the network) -> (offset, numel) in the arenas
         ps = [p for _, p in params]
         self._sig = (ps[0].data_ptr(), ps[-1].data_ptr())
         self._params = ps

@@ -116,7 +116,18 @@ class NeutrinoBase(_Base):
         named = list(self.named_parameters())
         groups = [{"params": [p for n, p in named if not any(s in n for s in no_decay)], "weight_decay": o.l2_penalty},
                   {"params": [p for n, p in named if any(s in n for s in no_decay)], "weight_decay": 0.0}]
-        optimizer = opt_cls(groups, lr=o.learning_rate)
+        optimizer = None
+        rt = self.network.hip_runtime() if hasattr(self.network, "hip_runtime") else None
+        first = next(self.parameters())
+        if opt_cls is torch.optim.AdamW and rt is not None and first.is_cuda and getattr(o, "hip_fused_optimizer", True):
+            # one fused launch over the flat arenas instead of 782 tensor updates.  Parameters that never get a
+            # gradient in the reference (grad None -> skipped by AdamW, no decay either) are frozen here as well.
+            from transformercvn.hip.optimizer import FlatAdamW
+            names = {id(p): n[len("network."):] for n, p in named if n.startswith("network.")}
+            frozen = ["prong_position_embedding"] + (["feature_embedding."] if o.disable_smart_features else [])
+            optimizer = FlatAdamW(groups, rt, names, lr=o.learning_rate, clip=o.gradient_clip, frozen=frozen)
+        if optimizer is None:
+            optimizer = opt_cls(groups, lr=o.learning_rate)
         if o.learning_rate_cycles < 1:
             sched = get_linear_schedule_with_warmup(optimizer, self.warmup_steps, self.total_steps)
         else:

@@ -129,6 +129,18 @@ int tcvn_focal_loss(const float* logits, const int64_t* targets, int rows, int c
                     float* d_logits, float* out2, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Fused optimizer step over flat arenas (replaces torch.optim.AdamW.step over 782 tensors + clip_grad_norm_:
+ * trainers/neutrino_base.py:88-152, train.py:140).  All pointers are device pointers of `n` fp32 elements.
+ * --------------------------------------------------------------------------------------------------------------- */
+/* out[0] = sum of squares of x (fp64 accumulation; partials: scratch of n_partials doubles, n_partials <= 1024 used). */
+int tcvn_grad_sumsq(const float* x, int64_t n, double* partials, int n_partials, float* out, void* stream);
+/* One AdamW step (decoupled weight decay).  weight_decay[i] < 0 freezes element i (parameter the reference's optimizer never
+ * touches).  grad_sumsq (device, may be NULL) and clip > 0 apply the global-norm clip coefficient min(1, clip/(norm+1e-6))
+ * to the gradient on the fly (the gradient arena itself is left as is).  step is 1-based. */
+int tcvn_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* weight_decay, int64_t n,
+                    float lr, float beta1, float beta2, float eps, int64_t step, const float* grad_sumsq, float clip, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg): when enabled, every convolution launch is bracketed by a HIP event pair on
  * its own stream.  tcvn_profile_get blocks on the record's end event; name is the kernel's label, flops the algorithmic
  * 2*M*N*K of that launch and bytes its algorithmic HBM traffic (operands once, results once).  Off by default; with a
