@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_pool0_bwd_vec(const Pool0BwdArgs a) {
 }
 
 constexpr int SW_MAXC = 4;
-__global__ __launch_bounds__(256) void k_stem_wgrad_sparse(const StemWgradArgs a) {
+__global__ __launch_bounds__(256, 2) void k_stem_wgrad_sparse(const StemWgradArgs a) {
     __shared__ float wacc[49 * SW_MAXC][64];
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 49 * SW_MAXC * 64; i += 256) (&wacc[0][0])[i] = 0.f;
@@ -183,28 +183,35 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd_bf16(const ConvFwdArgs g, i
     for (int i = tid; i < 2 * ST_PR * ST_PW * 4; i += 256) (&patch[0][0])[i] = 0;      // 4th channel + pitch padding stay zero
     double s1[2] = {0, 0}, s2[2] = {0, 0};
 
-    // patch staging: element e of patch row pr is input (iy0 + pr, ix0 + e/3, channel e%3); 21 x 111 elements, <= 10 per thread
+    // patch staging: element e of patch row pr is input (iy0 + pr, ix0 + e/3, channel e%3); 21 x 111 elements, <= 10 per thread.
+    // The (row, pixel, channel) of a thread's k-th element does not depend on the tile: decode once, outside the tile loop.
     constexpr int NE = ST_PR * 37 * 3, PER = (NE + 255) / 256;
+    int e_pr[PER], e_px[PER], e_goff[PER], e_loff[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + 256 * k;
+        const int pr = i / 111, e = i - pr * 111, px = e / 3, c = e - px * 3;
+        e_pr[k] = i < NE ? pr : -100000;                        // out-of-range elements fail the row test below
+        e_px[k] = px;
+        e_goff[k] = (pr * Win + px) * 3 + c;                     // element offset relative to the patch origin
+        e_loff[k] = (pr * ST_PW + px) * 4 + c;
+    }
     auto load_patch = [&](long tile, unsigned short (&v)[PER]) {
         const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
         const long n = tile / ((long)tiles_x * tiles_y);
         const int iy0 = 2 * ty * ST_TH - 3, ix0 = 2 * tx * ST_TW - 3;
+        const bf16* base = img + ((n * Hin + iy0) * (long)Win + ix0) * 3;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int i = tid + 256 * k;
-            const int pr = i / 111, e = i - pr * 111, px = e / 3, c = e - px * 3;
-            const int iy = iy0 + pr, ix = ix0 + px;
+            const int iy = iy0 + e_pr[k], ix = ix0 + e_px[k];
             v[k] = 0;
-            if (i < NE && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) v[k] = img[((n * Hin + iy) * Win + ix) * 3 + c];
+            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) v[k] = base[e_goff[k]];
         }
     };
     auto store_patch = [&](int buf, const unsigned short (&v)[PER]) {
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = tid + 256 * k;
-            const int pr = i / 111, e = i - pr * 111, px = e / 3, c = e - px * 3;
-            if (i < NE) patch[buf][(pr * ST_PW + px) * 4 + c] = v[k];
-        }
+        for (int k = 0; k < PER; ++k)
+            if (e_pr[k] >= 0) patch[buf][e_loff[k]] = v[k];
     };
 
     unsigned short pv[PER];
@@ -295,7 +302,7 @@ int pool0_bwd_vec(const Pool0BwdArgs& a, hipStream_t st) {
 
 int stem_wgrad_sparse(const StemWgradArgs& a, float* dWk, hipStream_t st) {
     if (a.Cpix > 3 || a.e.N > 64 || a.Kp < 49 * a.Cpix) return -2;
-    const int nb = 256;
+    const int nb = 512;                    // latency-bound walk over the hit list: two workgroups per CU
     if ((long)nb * a.e.N * a.Kp * 4 > a.slab_bytes) return -3;
     {
         ProfScope ps("k_stem_wgrad_sparse", 2.0 * a.nnz * 12.25 * a.Cpix * a.e.N, 0.0, st);
