@@ -12,7 +12,7 @@ namespace tcvn {
 
 namespace {
 
-constexpr int ROWS = 128;                      // pixels per stage
+constexpr int ROWS = 64;                       // pixels per stage; 64 KB of LDS per workgroup -> two workgroups per CU
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 __device__ __forceinline__ bf16x8_t tr_frag(const char* smem_base, int off_lo, int off_hi) {
@@ -39,7 +39,7 @@ __device__ __forceinline__ void dma_tile(char* smem_base, int buf_off, const bf1
     }
 }
 
-__global__ __launch_bounds__(256, 1) void k_gemm_tn_bf16(const GemmTnArgs g, long rows_per_split) {
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const GemmTnArgs g, long rows_per_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = ROWS * 256;                               // bytes of one operand tile
     // layout: L[0] L[1] R[0] R[1]
@@ -127,7 +127,11 @@ int gemm_tn_bf16(const GemmTnArgs& a, const char* label, hipStream_t st) {
     if (a.M <= 0) return 0;
     if (!gemm_tn_ok(a)) return -2;
     const int jt = cdiv(a.Rj, 128), it = cdiv(a.Li, 128);
-    int split = cdiv(256, jt * it);
+    int split = cdiv(512, jt * it);
+    if (a.slab != nullptr && a.Ci > 0) {                     // every slice needs its own Ci x ldc tile of the slab
+        const long cap = a.slab_bytes / ((long)a.Ci * a.ldc * 4);
+        if (split > cap) split = (int)cap;
+    }
     const long stages = (a.M + ROWS - 1) / ROWS;
     if (split > stages) split = (int)stages;
     if (split < 1) split = 1;
