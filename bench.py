@@ -210,6 +210,7 @@ def main():
                 "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n, "bytes_per_launch": by / n,
                 "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": pmc_traffic(top),
                 "measured": f"HIP events on the launch stream, all {n} launches of the {args.steps} timed steps",
+                "survey_avg_launch_ms": round(agg[top][1] / agg[top][0], 4),     # same kernel, embedders serialised (= rocprofv3's view)
                 "survey_ms_per_step": round(sum(a[1] for a in agg.values()), 2)}
     if world > 1:
         dist.barrier()
