@@ -8,6 +8,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- first: the library must bind to the HIP runtime PyTorch ships (one runtime per process); loading
+#                              /opt/rocm's copy ahead of torch's leaves this library without a device ("no ROCm-capable device")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libtcvn_hip.so"))
 
