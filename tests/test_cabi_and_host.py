@@ -137,3 +137,19 @@ def test_optimizer_groups_reproduce_reference_decay_mask():
     n_decay, n_nodecay = len(opt.param_groups[0]["params"]), len(opt.param_groups[1]["params"])
     assert (n_decay, n_nodecay) == (468, 314)            # SURVEY.md Appendix C, measured on the reference
     assert sch["interval"] == "step"
+
+
+def test_device_feeder_cpu_passthrough_attaches_host_counts():
+    """the feeder stages batches ahead and adds the host-side (max_prongs, n_prongs) pair."""
+    import torch
+    from oracle import tcvn_oracle as O
+    from transformercvn.hip.feeder import DeviceFeeder, host_counts
+    cfg = O.tutorial_config()
+    batches = [O.synthetic_batch([2, 4, 1], 5 + i, cfg) for i in range(4)]
+    out = list(DeviceFeeder(batches, "cpu", depth=2))
+    assert len(out) == 4
+    for src, got in zip(batches, out):
+        assert len(got) == 11 and got[10] == host_counts(src[7])
+        assert got[10] == (int(src[7].sum(1).max()), int(src[7].sum()))
+        for a, b in zip(src[:10], got[:10]):
+            assert torch.equal(a, b)

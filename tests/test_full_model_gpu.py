@@ -91,3 +91,32 @@ def test_cpu_tensors_fail_loudly():
     model = build_trainer(cfg, None, device=None)
     with pytest.raises(RuntimeError):
         model.shared_step(batch)
+
+
+@pytest.mark.gpu
+def test_device_feeder_feeds_training_steps():
+    """batches staged by the feeder (pinned, copy stream, host-side prong counts) give the same loss as batches
+    moved synchronously."""
+    from transformercvn.hip.feeder import DeviceFeeder
+    cfg, over, batch, g = load_case("small_b3")
+    cfg = train_cfg(over)
+    sd = O.fill_state(cfg, int(g["weight_seed"]))
+    batches = [O.synthetic_batch([2, 3, 1], 21 + i, cfg) for i in range(3)]
+    model = build_trainer(cfg, sd)
+    model.train()
+    rt = model.network.hip_runtime()
+    direct = []
+    for b in batches:
+        rt.zero_grad()
+        direct.append(model.training_step(to_device(b), 0).item())
+    model2 = build_trainer(cfg, sd)
+    model2.train()
+    rt2 = model2.network.hip_runtime()
+    fed = []
+    for b in DeviceFeeder(batches, "cuda", depth=2):
+        assert len(b) == 11 and b[2].is_cuda and b[2].dtype == torch.int32
+        rt2.zero_grad()
+        fed.append(model2.training_step(b, 0).item())
+    assert len(fed) == 3
+    for a, b in zip(direct, fed):
+        assert abs(a - b) <= 1e-5 * abs(a), (direct, fed)
