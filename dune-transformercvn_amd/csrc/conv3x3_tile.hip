@@ -169,6 +169,139 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_bf16(const ConvFwdArgs g
     }
 }
 
+// Ring variant: a workgroup walks CONSECUTIVE tiles, so tile t+1's image shares its first rows() - 128 rows with tile t's.
+// The LDS image is a ring of 512 rows (padded position g -> row (g - g_org) & 511, g_org = first row of the workgroup's first
+// tile): per tile only the 128 new rows are fetched (32 KB instead of 128 + 2*(W+3) rows = 70 KB at W = 69).  Measured on the
+// strip kernel above: the LDS-DMA fill alone cost 173 of the 335 us of a block-1 launch.  Needs rows() + 128 <= 512.
+constexpr int RING = 512;
+__global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_ring_bf16(const ConvFwdArgs g, int n_img, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PadGeom q(n_img, g.H, g.W);
+    const int nrows4 = (q.rows() + 3) & ~3;
+    int* tbl = reinterpret_cast<int*>(smem + RING * 256);                   // [RING] pixel index per ring row
+    double* red = reinterpret_cast<double*>(smem + RING * 256 + RING * 4);  // [4][32][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
+    const bf16* __restrict__ YA = reinterpret_cast<const bf16*>(g.Aact);
+    const char* __restrict__ zeros = reinterpret_cast<const char*>(g.zeros);
+    const bf16* __restrict__ Wf = reinterpret_cast<const bf16*>(g.Wfrag) + lane * 8;
+    bf16* __restrict__ Out = reinterpret_cast<bf16*>(g.Out);
+    const int nb = gridDim.x, base = ntiles / nb, rem = ntiles % nb;
+    const int t0 = blockIdx.x * base + min((int)blockIdx.x, rem), t1 = t0 + base + ((int)blockIdx.x < rem ? 1 : 0);
+    const int g_org = t0 * TP - q.halo;
+    const bool nok = r < g.N;
+    const float bias = nok ? g.bias[r] : 0.f;
+    const bool drop = g.drop_p > 0.f;
+    const uint32_t dkey = drop_key(g.seed, g.stream_id);
+
+    bf16x8_t bw[72];
+#pragma unroll
+    for (int i = 0; i < 72; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + i * 512);
+
+    double s1 = 0, s2 = 0;
+    // rows [row0, row0 + n) of this workgroup's row space (row 0 = g_org); ring slot = row & 511
+    auto fill_rows = [&](int row0, int n) {
+        for (int i = tid; i < n; i += 256) tbl[(row0 + i) & (RING - 1)] = pix_of(q, g_org + row0 + i, invWp, invHp);
+    };
+    auto dma_rows = [&](int row0, int n) {                       // n multiple of 4; 4 rows (1 KiB) per wave instruction
+        const int rsub = lane >> 4, slot = lane & 15;
+        for (int rg = wave; rg * 4 < n; rg += 4) {
+            const int ring_row = (row0 + rg * 4) & (RING - 1);   // row0 and RING are multiples of 4: a group never wraps
+            const int rr = ring_row + rsub;
+            const int m = tbl[rr];
+            const char* src = m >= 0 ? reinterpret_cast<const char*>(YA + (long)m * 128) + ((slot ^ (rr & 15)) << 4) : zeros + (slot << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + ring_row * 256), 16, 0, 0);
+        }
+    };
+    if (t0 < t1) fill_rows(0, nrows4);
+    if (t0 + 1 < t1) fill_rows(nrows4, TP);
+    __syncthreads();
+    if (t0 < t1) dma_rows(0, nrows4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        const int k128 = (t - t0) * TP;                          // row of this tile's first image row
+        if (t + 1 < t1 && !(g.dbg & 1)) dma_rows(nrows4 + k128, TP);     // the next tile's 128 new rows, under this tile's MFMAs
+        // two accumulator chains (even / odd k-steps): a dependent MFMA chain issues one MFMA per ~54 cycles, two independent
+        // chains keep the matrix pipe at its 32-cycle cadence
+        f32x16 acc, acc2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc2[e] = 0.f; }
+        asm volatile("s_nop 4" : "+a"(acc), "+a"(acc2));   // accvgpr writes -> first MFMA (inside asm) needs its wait states
+        const int lrow0 = k128 + wave * 32 + r + q.halo;
+        bf16x8_t af[2][8];
+        {
+            const int lr = (lrow0 - q.Wp - 1) & (RING - 1);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                af[0][ks] = *reinterpret_cast<const bf16x8_t*>(smem + lr * 256 + (((2 * ks + h) ^ (lr & 15)) << 4));
+        }
+        if (!(g.dbg & 2))
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) {
+                const int lr = (lrow0 + ((tap + 1) / 3 - 1) * q.Wp + ((tap + 1) % 3 - 1)) & (RING - 1);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    af[(tap + 1) & 1][ks] = *reinterpret_cast<const bf16x8_t*>(smem + lr * 256 + (((2 * ks + h) ^ (lr & 15)) << 4));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {      // hazard padding: see k_conv3x3_fwd_bf16
+                if (ks & 1) {
+                    if (tap < 7) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc2) : "v"(af[tap & 1][ks]), "a"(bw[tap * 8 + ks]));
+                    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc2) : "v"(af[tap & 1][ks]), "v"(bw[tap * 8 + ks]));
+                } else {
+                    if (tap < 7) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af[tap & 1][ks]), "a"(bw[tap * 8 + ks]));
+                    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af[tap & 1][ks]), "v"(bw[tap * 8 + ks]));
+                }
+            }
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc), "+a"(acc2));
+        long cur_grp = -1;
+        uint32_t bits = 0;
+        float f1 = 0.f, f2 = 0.f;                       // this tile's 16 values per lane in fp32, folded into fp64 once per tile
+        int mrow[16];                                    // all 16 table reads in one batch (one LDS wait, not one per element)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mrow[e] = tbl[(k128 + q.halo + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) & (RING - 1)];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = mrow[e];
+            if (m >= 0 && nok && !(g.dbg & 4)) {
+                float v = acc[e] + acc2[e] + bias;
+                if (drop) {
+                    if ((m >> 1) != cur_grp) { cur_grp = m >> 1; bits = drop_bits(dkey, m, r, g.N); }
+                    v *= drop_pick(bits, m, g.drop_p);
+                }
+                const bf16 o = f2bf(v);
+                Out[(long)m * g.ldo + g.n_off + r] = o;
+                const float x = bf2f(o);
+                f1 += x; f2 = fmaf(x, x, f2);
+            }
+        }
+        s1 += (double)f1; s2 += (double)f2;
+        if (t + 2 < t1) fill_rows(nrows4 + k128 + TP, TP);        // table of the rows the next iteration will fetch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (g.part != nullptr) {
+        double a = s1, b = s2;
+        a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+        if (lane < 32) { red[(wave * 32 + lane) * 2] = a; red[(wave * 32 + lane) * 2 + 1] = b; }
+        __syncthreads();
+        if (tid < g.N) {
+            double x = 0, y = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { x += red[(w * 32 + tid) * 2]; y += red[(w * 32 + tid) * 2 + 1]; }
+            g.part[((long)blockIdx.x * g.N + tid) * 2] = x;
+            g.part[((long)blockIdx.x * g.N + tid) * 2 + 1] = y;
+        }
+    }
+}
+size_t fwd_ring_smem() { return RING * 256 + RING * 4 + 4 * 32 * 16; }
+
 size_t fwd_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return 2 * r4 * 256 + 3 * r4 * 4 + 4 * 32 * 16; }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -709,6 +842,17 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
     ConvFwdArgs b = a;
     static const int dbg = getenv("TCVN_DBG") ? atoi(getenv("TCVN_DBG")) : 0;
     b.dbg = dbg;
+    if (((q.rows() + 3) & ~3) + TP <= RING && !(dbg & 32)) {       // consecutive tiles per workgroup, ring image (TCVN_DBG=32: strips)
+        static bool attr2 = false;
+        if (!attr2) {
+            TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_fwd_ring_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(k_conv3x3_fwd_ring_bf16, dim3(nb), dim3(256), fwd_ring_smem(), st, b, n_img, ntiles);
+        TCVN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_conv3x3_fwd_bf16, dim3(nb), dim3(256), smem, st, b, n_img, ntiles, (nb >= 8 && nb % 8 == 0 && !(dbg & 8)) ? 1 : 0);
     TCVN_LAUNCH_CHECK();
     return 0;
