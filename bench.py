@@ -99,10 +99,18 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    # rehearsal on a one-GPU box (control flow of the multi-rank path only): TCVN_BENCH_REHEARSAL=1 puts every rank on
+    # cuda:0 and exchanges over gloo; the real run is one rank per GPU over RCCL ("nccl")
+    rehearsal = os.environ.get("TCVN_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from transformercvn.options import Options
     from transformercvn.network.trainers.neutrino_full_dense_trainer import NeutrinoFullDenseTrainer
@@ -137,38 +145,42 @@ def main():
         step()
     torch.cuda.synchronize()
 
-    # Untimed survey step (rank 0): every convolution-class launch bracketed by HIP events on its own stream, embedders
-    # serialised on one stream so that the per-kernel times are not smeared by the overlap.  It names the dominant kernel.
+    # Untimed survey step: every convolution-class launch bracketed by HIP events on its own stream, embedders serialised on
+    # one stream so that the per-kernel times are not smeared by the overlap.  It names the dominant kernel.  Every rank runs
+    # the same two extra steps (they contain collectives); only rank 0 records.
     agg, kernels, top = {}, None, None
     profiled = rank == 0 and not args.no_profile
-    if profiled:
+    if not args.no_profile:
         rt.overlap_embedders = False
-        _lib.lib.tcvn_profile_filter(None)
-        _lib.lib.tcvn_profile_reset()
-        _lib.lib.tcvn_profile_enable(1)
+        if profiled:
+            _lib.lib.tcvn_profile_filter(None)
+            _lib.lib.tcvn_profile_reset()
+            _lib.lib.tcvn_profile_enable(1)
         step()
         torch.cuda.synchronize()
-        _lib.lib.tcvn_profile_enable(0)
         rt.overlap_embedders = True
-        records = _lib.profile_records()
-        if args.dump_records:
-            with open(args.dump_records, "w") as f:
-                json.dump(records, f)
-        for name, ms, fl, by in records:
-            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
-            a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
-        _lib.lib.tcvn_profile_reset()
-        kernels = sorted(({"kernel": k, "launches": a[0], "ms": round(a[1], 3), "avg_ms": round(a[1] / a[0], 4),
-                           "tflops": round(a[2] / a[1] / 1e9, 2) if a[1] > 0 else 0.0,
-                           "gbps": round(a[3] / a[1] / 1e6, 1) if a[1] > 0 else 0.0} for k, a in agg.items()),
-                         key=lambda r: -r["ms"])
-        top = kernels[0]["kernel"]
-        # the timed region below records the dominant kernel only (two events per launch of that one kernel)
-        _lib.lib.tcvn_profile_filter(top.encode())
-        _lib.lib.tcvn_profile_enable(1)
+        if profiled:
+            _lib.lib.tcvn_profile_enable(0)
+            records = _lib.profile_records()
+            if args.dump_records:
+                with open(args.dump_records, "w") as f:
+                    json.dump(records, f)
+            for name, ms, fl, by in records:
+                a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+                a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
+            _lib.lib.tcvn_profile_reset()
+            kernels = sorted(({"kernel": k, "launches": a[0], "ms": round(a[1], 3), "avg_ms": round(a[1] / a[0], 4),
+                               "tflops": round(a[2] / a[1] / 1e9, 2) if a[1] > 0 else 0.0,
+                               "gbps": round(a[3] / a[1] / 1e6, 1) if a[1] > 0 else 0.0} for k, a in agg.items()),
+                             key=lambda r: -r["ms"])
+            top = kernels[0]["kernel"]
+            # the timed region below records the dominant kernel only (two events per launch of that one kernel)
+            _lib.lib.tcvn_profile_filter(top.encode())
+            _lib.lib.tcvn_profile_enable(1)
         step()                                       # settle after the serialised survey step
         torch.cuda.synchronize()
-        _lib.lib.tcvn_profile_reset()
+        if profiled:
+            _lib.lib.tcvn_profile_reset()
 
     note("timed steps ...")
     if world > 1:
@@ -234,7 +246,7 @@ def main():
         if roof:
             out["roofline"] = roof
             out["kernels"] = kernels[:8]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only
             note("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline(host_threads())
         print(json.dumps(out))
