@@ -243,7 +243,11 @@ bool gemm_nt_ok(const GemmNtArgs& a) {
            (reinterpret_cast<uintptr_t>(a.Gout) & 15) == 0;
 }
 int gemm_nt_nblk(const GemmNtArgs& a) {
-    const int rows = nt_rows(a), cap = rows == 64 ? 512 : 256;          // two workgroups per CU for the 64-row tiles
+    const int rows = nt_rows(a), nn = cdiv(a.N, 128);
+    // resident capacity: two workgroups per CU for the 64-row tiles, shared by the nn column tiles of the grid -- more
+    // workgroups than that only queue up and pay their prologue (weight fragments, tables) again
+    int cap = (rows == 64 ? 512 : 256) / nn;
+    if (cap < 64) cap = 64;
     const long mt = (a.M + rows - 1) / rows;
     return (int)(mt < cap ? mt : cap);
 }
