@@ -233,7 +233,7 @@ static int nt_max_ksteps(int epi) { return epi == EPI_FWD ? KS_FWD : epi == EPI_
 static int nt_rows(const GemmNtArgs& a) {
     if (a.epi == EPI_DGRAD) return 64;
     if (a.epi == EPI_DGRAD_POOL) return a.Kp <= KS_POOL_SMALL * 16 ? 64 : 128;
-    return 128;
+    return a.Kp <= KS_FWD_SMALL * 16 ? 64 : 128;
 }
 bool gemm_nt_ok(const GemmNtArgs& a) {
     if (!a.A || !a.Wfrag || !a.zeros || (a.lda & 7) || (a.K & 7) || a.Kp > nt_max_ksteps(a.epi) * 16 || (a.Kp & 15)) return false;
@@ -260,7 +260,7 @@ int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         const void* fns[6] = {reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128>),
-                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 128>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64>),
                               reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD, 64>),
                               reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD_SMALL, 64>),
                               reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL, 128>),
@@ -273,7 +273,7 @@ int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
     const double bytes = (double)a.M * 2.0 * (a.K + (a.epi == EPI_FWD ? (double)a.N : 3.0 * px * a.N));
     ProfScope ps(label, 2.0 * a.M * (double)a.N * a.K, bytes, st);
     const dim3 grid(gemm_nt_nblk(a), cdiv(a.N, 128));
-    if (a.epi == EPI_FWD && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 128>), grid, dim3(256), smem, st, a);
+    if (a.epi == EPI_FWD && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64>), grid, dim3(256), smem, st, a);
     else if (a.epi == EPI_FWD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128>), grid, dim3(256), smem, st, a);
     else if (a.epi == EPI_DGRAD && a.Kp <= KS_DGRAD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD_SMALL, 64>), grid, dim3(256), smem, st, a);
     else if (a.epi == EPI_DGRAD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD, 64>), grid, dim3(256), smem, st, a);
