@@ -890,10 +890,10 @@ int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st) {
                            (nb >= 8 && nb % 8 == 0) ? 1 : 0);
         TCVN_LAUNCH_CHECK();
     }
-    int rc = slab_reduce(a.slab, nb, 9 * 128 * 32, a.dWk, st);
-    if (rc) return rc;
-    // bias partials [nb][32] -> dbias[0:N)  (the 32-wide rows are zero beyond N)
-    return slab_reduce(a.slab + (long)nb * (9 * 128 * 32), nb, a.e.N, a.dbias, st, 32);
+    // weight partials [nb][9*128*32] -> dWk and bias partials [nb][32] -> dbias[0:N) (32-wide rows, zero beyond N): one launch
+    SlabJob jb{};
+    if (a.dbias != nullptr) jb = slab_job(a.slab + (long)nb * (9 * 128 * 32), nb, a.e.N, a.dbias, 32);
+    return slab_reduce2(slab_job(a.slab, nb, 9 * 128 * 32, a.dWk, 0), jb, st);
 }
 
 }  // namespace tcvn

@@ -13,6 +13,7 @@ using namespace tcvn;
 namespace {
 constexpr float kEps = 1e-5f;
 constexpr long kSlabBytes = 48L << 20;      // per-workgroup partial weight gradients (<= 256 x 147 KB) and column sums
+constexpr long kSlabGemmBytes = 44L << 20;  // GEMM slabs; the tail [44 MB, 48 MB) holds the bias column-sum partials (<= 1024 x 512 floats)
 struct Bump {
     long off;
     long take(long bytes) { long o = off; off += round_up(bytes, 256); return o; }
@@ -153,10 +154,11 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             const int Nt8 = (int)round_up(Nt, 8);
             if (L.XP[bi] >= 0) {
                 // materialise the output gradient once (+ bias gradient), then dW = ET^T x XP on the TN GEMM
-                EffMatArgs em{e, Mn, ws + L.ey, Nt8, grad[bg.tb], reinterpret_cast<float*>(ws + L.slab)};
+                SlabJob bias_job{};
+                EffMatArgs em{e, Mn, ws + L.ey, Nt8, grad[bg.tb], reinterpret_cast<float*>(ws + L.slab + kSlabGemmBytes), &bias_job};
                 if ((rc = eff_materialize_bf16(em, st))) return rc;
                 GemmTnArgs ga{ws + L.ey, Nt8, Nt8, ws + L.XP[bi], bg.ld, bg.ld, Mn, gw_of(bg.tw), ef.Kp, ws + L.zeros,
-                              reinterpret_cast<float*>(ws + L.slab), kSlabBytes, Nt};
+                              reinterpret_cast<float*>(ws + L.slab), kSlabGemmBytes, Nt, bias_job};
                 if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<transition>", st))) return rc;
             } else if ((rc = conv_wgrad(w, st))) return rc;
             if (L.XP[bi] >= 0) {
@@ -223,11 +225,12 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 w.fa.Kp = ef.Kp; w.fa.C = ls.cin; w.fa.H = bg.H; w.fa.W = bg.W;
                 w.fa.sc = sc_of(ls.n1); w.fa.sh = sh_of(ls.n1); w.fa.sl = data[ls.a1];
                 if (L.XA[bi][l] >= 0) {
-                    EffMatArgs em{e1, M, ws + L.ey, mid, grad[ls.b1], reinterpret_cast<float*>(ws + L.slab)};
+                    SlabJob bias_job{};     // bias column sums: reduced together with the weight-gradient slab below
+                    EffMatArgs em{e1, M, ws + L.ey, mid, grad[ls.b1], reinterpret_cast<float*>(ws + L.slab + kSlabGemmBytes), &bias_job};
                     if ((rc = eff_materialize_bf16(em, st))) return rc;
                     const int cin8 = (int)round_up(ls.cin, 8);
                     GemmTnArgs ga{ws + L.ey, mid, mid, ws + L.XA[bi][l], cin8, cin8, M, gw_of(ls.w1), ef.Kp, ws + L.zeros,
-                                  reinterpret_cast<float*>(ws + L.slab), kSlabBytes, mid};
+                                  reinterpret_cast<float*>(ws + L.slab), kSlabGemmBytes, mid, bias_job};
                     if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<conv1>", st))) return rc;
                 } else if ((rc = conv_wgrad(w, st))) return rc;
             }

@@ -169,27 +169,31 @@ __global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a, int wlog) {
     }
 }
 
-// dst[i] += sum_s slab[s*stride + i]: block = 64 columns x 4 slab lanes; grid.y splits the slabs (<= 16 atomics per element)
-__global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slab, int nslab, long count, float* dst, long stride,
-                                                     int per_y) {
+// dst[i] += sum_s slab[s*stride + i]: block = 64 columns x 4 slab lanes; grid.y splits the slabs (<= 16 atomics per element);
+// grid.z selects one of two independent jobs (e.g. a weight-gradient slab and the bias column sums of the same layer: one
+// launch instead of two -- these launches sit at the ~5 us dispatch floor)
+__global__ __launch_bounds__(256) void k_slab_reduce(const SlabJob j0, const SlabJob j1) {
+    const SlabJob& j = blockIdx.z == 0 ? j0 : j1;
     __shared__ float red[4][64];
     const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 64 + cx;
-    const int s0 = blockIdx.y * per_y, s1 = min(nslab, s0 + per_y);
+    if ((long)blockIdx.x * 64 >= j.count || (int)blockIdx.y >= j.ny) return;          // uniform per workgroup
+    const int s0 = blockIdx.y * j.per_y, s1 = min(j.nslab, s0 + j.per_y);
+    const float* __restrict__ slab = j.slab;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (i < count) {
+    if (i < j.count) {
         int k = s0 + sg;
         for (; k + 12 < s1; k += 16) {
-            a0 += slab[(long)k * stride + i]; a1 += slab[(long)(k + 4) * stride + i];
-            a2 += slab[(long)(k + 8) * stride + i]; a3 += slab[(long)(k + 12) * stride + i];
+            a0 += slab[(long)k * j.stride + i]; a1 += slab[(long)(k + 4) * j.stride + i];
+            a2 += slab[(long)(k + 8) * j.stride + i]; a3 += slab[(long)(k + 12) * j.stride + i];
         }
-        for (; k < s1; k += 4) a0 += slab[(long)k * stride + i];
+        for (; k < s1; k += 4) a0 += slab[(long)k * j.stride + i];
     }
     red[sg][cx] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (sg == 0 && i < count) {
+    if (sg == 0 && i < j.count) {
         const float v = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
-        if (gridDim.y == 1) dst[i] += v; else atomicAdd(dst + i, v);
+        if (j.ny == 1) j.dst[i] += v; else atomicAdd(j.dst + i, v);
     }
 }
 
@@ -247,18 +251,32 @@ int eff_materialize_bf16(const EffMatArgs& a, hipStream_t st) {
     if (a.colsum != nullptr && a.slab == nullptr) return -3;
     hipLaunchKernelGGL(k_eff_mat, dim3(nb), dim3(256), 0, st, a, wlog);
     TCVN_LAUNCH_CHECK();
-    if (a.colsum != nullptr) return slab_reduce(a.slab, nb, e.N, a.colsum, st);
+    if (a.colsum != nullptr) {
+        if (a.deferred != nullptr) *a.deferred = slab_job(a.slab, nb, e.N, a.colsum, 0);      // folded into the caller's next reduction
+        else return slab_reduce(a.slab, nb, e.N, a.colsum, st);
+    }
     return 0;
 }
 
-int slab_reduce(const float* slab, int nslab, long count, float* dst, hipStream_t st, long stride) {
-    if (count <= 0 || nslab <= 0) return 0;
+SlabJob slab_job(const float* slab, int nslab, long count, float* dst, long stride) {
+    SlabJob j{slab, dst, nslab, count, stride > 0 ? stride : count, 1, 1};
+    if (count <= 0 || nslab <= 0) { j.count = 0; return j; }
     int ny = cdiv(nslab, 64);
     if (ny > 16) ny = 16;
-    const int per_y = cdiv(nslab, ny);
-    hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(count, 64), ny), dim3(256), 0, st, slab, nslab, count, dst, stride > 0 ? stride : count, per_y);
+    j.ny = ny; j.per_y = cdiv(nslab, ny);
+    return j;
+}
+int slab_reduce2(const SlabJob& a, const SlabJob& b, hipStream_t st) {
+    if (a.count <= 0 && b.count <= 0) return 0;
+    const long cmax = a.count > b.count ? a.count : b.count;
+    const int nymax = a.ny > b.ny ? a.ny : b.ny;
+    hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(cmax, 64), nymax, b.count > 0 ? 2 : 1), dim3(256), 0, st, a, b);
     TCVN_LAUNCH_CHECK();
     return 0;
+}
+int slab_reduce(const float* slab, int nslab, long count, float* dst, hipStream_t st, long stride) {
+    SlabJob none{};
+    return slab_reduce2(slab_job(slab, nslab, count, dst, stride), none, st);
 }
 
 int unpack_wgrads(const UnpackDesc* d_descs, int n, hipStream_t st) {

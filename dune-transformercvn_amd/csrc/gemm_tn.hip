@@ -148,7 +148,7 @@ int gemm_tn_bf16(const GemmTnArgs& a, const char* label, hipStream_t st) {
         hipLaunchKernelGGL(k_gemm_tn_bf16, dim3(jt, it, split), dim3(256), 4 * ROWS * 256, st, a, rows);
         TCVN_LAUNCH_CHECK();
     }
-    return slab_reduce(a.slab, split, (long)a.Ci * a.ldc, a.C, st);
+    return slab_reduce2(slab_job(a.slab, split, (long)a.Ci * a.ldc, a.C, 0), a.extra, st);
 }
 
 }  // namespace tcvn

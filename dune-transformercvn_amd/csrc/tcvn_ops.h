@@ -167,9 +167,14 @@ int pool0_bwd(const Pool0BwdArgs& a, hipStream_t st);
 int pool0_bwd_grid(int n_img, int Hin, int Win);
 
 // bf16 TN GEMM over pixels (gemm_tn.hip): C[i][j] += sum_m L[m][i] * R[m][j]
+// one reduction job: dst[i] += sum_{s < nslab} slab[s*stride + i], i < count
+struct SlabJob { const float* slab; float* dst; int nslab; long count, stride; int ny, per_y; };
+SlabJob slab_job(const float* slab, int nslab, long count, float* dst, long stride);
+int slab_reduce2(const SlabJob& a, const SlabJob& b, hipStream_t st);          // two independent jobs in one launch (b may be empty)
 struct GemmTnArgs { const void* L; long ldl; int Li; const void* R; long ldr; int Rj; long M; float* C; long ldc; const void* zeros;
                     float* slab; long slab_bytes;        // slab: scratch for per-slice partial tiles (no contended atomics)
-                    int Ci; };                           // rows of C written (<= Li; L columns in [Ci, Li) are zero padding)
+                    int Ci;                              // rows of C written (<= Li; L columns in [Ci, Li) are zero padding)
+                    SlabJob extra; };                    // optional second reduction folded into this GEMM's slab reduction
 // dst[i] += sum_s slab[s*count + i]   (deterministic reduction of per-workgroup partial results)
 int slab_reduce(const float* slab, int nslab, long count, float* dst, hipStream_t st, long stride = 0);   // stride 0 = count
 bool gemm_tn_ok(const GemmTnArgs& a);
@@ -195,7 +200,8 @@ int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st);
 
 // Materialise an effective gradient: Out[m][n] = bf16(drop * (G[m][c_off+n] + P[n]*X[m][c_off+n] + Q[n])), n < e.N;
 // optionally colsum[n] += sum_m Out[m][n] (bias gradient of the producing convolution).
-struct EffMatArgs { EffSrc e; long M; void* Out; long ldo; float* colsum; float* slab; };   // slab: >= 2048*N floats when colsum
+struct EffMatArgs { EffSrc e; long M; void* Out; long ldo; float* colsum; float* slab;   // slab: >= 2048*N floats when colsum
+                    SlabJob* deferred; };   // when set: the column-sum reduction is returned as a job instead of being launched
 int eff_materialize_bf16(const EffMatArgs& a, hipStream_t st);
 
 // XP[m'][c] = bf16( 1/4 sum_{2x2} prelu(D[pixel][c]*sc + sh, sl) )  (pooled activation in front of a transition's 1x1 conv)
