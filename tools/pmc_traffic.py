@@ -16,7 +16,7 @@ LABELS = {            # bench.py label -> substring of the demangled kernel name
     "k_gemm_nt_bf16<dgrad1x1>": "k_gemm_nt_bf16<1, ",
     "k_gemm_nt_bf16<dgradtrans>": "k_gemm_nt_bf16<2, ",
     "k_conv3x3_dgrad_bf16": "k_conv3x3_dgrad",
-    "k_conv3x3_fwd_bf16": "k_conv3x3_fwd_bf16",
+    "k_conv3x3_fwd_bf16": "k_conv3x3_fwd_",
     "k_conv3x3_wgrad_bf16": "k_conv3x3_wgrad_bf16",
     "k_stem_fwd_bf16": "k_stem_fwd_bf16",
     "k_act_bf16": "k_act_bf16",
