@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad_bf16(const ConvDgradAr
 // __syncthreads() would drain the DMA and the prefetched loads (its fence waits for vmcnt(0)).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradArgs g, int n_img, int ntiles, int swz) {
+__global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradArgs g, int n_img, int ntiles, int swz, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const EffSrc& e = g.e;
     const PadGeom q(n_img, g.H, g.W);
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
         for (int rr = er0; rr < nr; rr += 64) {
             const int m = tbl[cur * nr + rr];
             u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (m >= 0) {
+            if (m >= 0 && !(dbg & 8)) {
                 const u16x8 gv = *reinterpret_cast<const u16x8*>(smem + o_rg + rr * 64 + ec * 16);
                 const u16x8 xv = *reinterpret_cast<const u16x8*>(smem + o_rd + rr * 64 + ec * 16);
 #pragma unroll
@@ -706,6 +706,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+        if (!(dbg & 2))
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int base = q.halo - ((tap / 3 - 1) * q.Wp + (tap % 3 - 1)) + r;      // source position = p - shift(tap)
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
             for (int i = 0; i < 2; ++i) {
                 const int rr = e_r0 + 16 * i;
                 const int m = tbl[cur * nr + q.halo + pass * 32 + rr];
-                if (m >= 0) {
+                if (m >= 0 && !(dbg & 4)) {
                     const float4 ca = *reinterpret_cast<const float4*>(Cs + rr * CLD3 + e_c8 * 8);
                     const float4 cc = *reinterpret_cast<const float4*>(Cs + rr * CLD3 + e_c8 * 8 + 4);
                     const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cc.x, cc.y, cc.z, cc.w};
@@ -926,7 +927,8 @@ int conv3x3_dgrad_tile(const ConvDgradArgs& a, hipStream_t st) {
             TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_dgrad2_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             attr = true;
         }
-        hipLaunchKernelGGL(k_conv3x3_dgrad2_bf16, dim3(nb), dim3(256), dgrad2_smem(q), st, a, n_img, ntiles, (nb >= 8 && nb % 8 == 0) ? 1 : 0);
+        static const int dbgd = getenv("TCVN_DBG") ? atoi(getenv("TCVN_DBG")) : 0;
+        hipLaunchKernelGGL(k_conv3x3_dgrad2_bf16, dim3(nb), dim3(256), dgrad2_smem(q), st, a, n_img, ntiles, (nb >= 8 && nb % 8 == 0) ? 1 : 0, dbgd);
         TCVN_LAUNCH_CHECK();
         return 0;
     }

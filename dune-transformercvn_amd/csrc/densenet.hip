@@ -13,6 +13,7 @@
 #include "../../include/tcvn_hip.h"
 #include "tcvn_ops.h"
 #include "tcvn_rows.h"
+#include <cstdlib>
 #include "densenet_plan.h"
 
 using namespace tcvn;
@@ -129,7 +130,9 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
         std::vector<long> xas;
         for (int l = 0; l < bg.L; ++l) {
             const int cin = bg.C0 + l * cfg.growth;
-            xas.push_back(fast1_ok(cin) ? b.take(M * round_up(cin, 8) * esz) : -1);    // row stride round_up(cin, 8), zero padded
+            // >= 0 marks the bf16 GEMM path; the activated copy itself is skipped with TCVN_XA_ONTHEFLY (then the GEMMs
+            // transform the raw concat buffer in LDS)
+            xas.push_back(fast1_ok(cin) ? b.take(xa_materialize() ? M * round_up(cin, 8) * esz : 0) : -1);
         }
         L.XA.push_back(xas);
         const bool tfast = bg.has_trans && fastt_ok(bg.Ctot);
@@ -192,6 +195,12 @@ long DenseNetPlan::wk_bytes() const {
 bool DenseNetPlan::fast1_ok(int cin) const {
     const int mid = cfg.bn_size * cfg.growth;
     return cfg.mode == MODE_BF16 && conv3x3_tile_enabled() && mid % 8 == 0 && mid <= 256 && round_up(cin, 32) <= 640;
+}
+bool tcvn::xa_materialize() {
+    static const bool on = getenv("TCVN_XA_ONTHEFLY") == nullptr;   // default: write prelu(bn1(x)) to HBM once per layer.  A/B on
+    // MI355X (B=32 x 8 prongs): transforming the raw tile in LDS inside the two GEMMs instead saves the copy (2.4 GB, 1.5 ms of
+    // k_act_bf16) but costs more than it saves at one or two waves per SIMD: fwd1x1 2.2 -> 4.8 ms, dW1 2.0 -> 3.0 ms, step 29.3 -> 30.7 ms
+    return on;
 }
 bool DenseNetPlan::fastt_ok(int Ctot) const {
     return cfg.mode == MODE_BF16 && conv3x3_tile_enabled() && round_up(Ctot, 32) <= 640 && Ctot / 2 <= 512;
@@ -379,7 +388,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             if ((rc = link(ls.n1, part, new_nblk, new_ld, new_c0, new_n, bstatD, M))) return rc;
             const bool fast1 = L.XA[bi][l] >= 0;
             const int cin8 = (int)round_up(ls.cin, 8);
-            if (fast1) {     // activated copy of the 1x1 input: operand of the bf16 GEMMs (forward and weight gradient)
+            if (fast1 && xa_materialize()) {     // activated copy of the 1x1 input: operand of the bf16 GEMMs (forward, weight gradient)
                 Tab t1 = tab(ls.n1);
                 ActArgs act{D, bg.ld, M, ls.cin, t1.sc, t1.sh, data[ls.a1], ws + L.XA[bi][l], cin8};
                 if ((rc = act_bf16(act, st))) return rc;
@@ -388,6 +397,10 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 const WkEntry& e = wk_find(ls.w1, 0, 1);
                 GemmNtArgs a{};
                 a.epi = EPI_FWD; a.A = ws + L.XA[bi][l]; a.lda = cin8; a.K = cin8; a.M = M; a.N = mid;
+                if (!xa_materialize()) {      // raw concat buffer in, BatchNorm + PReLU applied to every landed LDS tile
+                    Tab t1 = tab(ls.n1);
+                    a.A = D; a.lda = bg.ld; a.asc = t1.sc; a.ash = t1.sh; a.asl = data[ls.a1]; a.Kreal = ls.cin;
+                }
                 a.Wfrag = ws + L.wk + e.off; a.Kp = e.Kp; a.zeros = ws + L.zeros; a.bias = data[ls.b1];
                 a.Out = ws + L.Y[bi][l]; a.ldo = mid; a.n_off = 0; a.part = train ? part : nullptr; a.nblk = gemm_nt_nblk(a);
                 if ((rc = gemm_nt_bf16(a, "k_gemm_nt_bf16<fwd1x1>", st))) return rc;
@@ -508,7 +521,7 @@ int DenseNetPlan::tap(int n, const char* name, long* off, int* tn, int* th, int*
         b -= 1;
         if (b < 0 || b >= (int)blocks.size() || l < 0 || l >= blocks[b].L) return -1;
         const bool xa = s[0] == 'x';
-        if ((xa && (L.XA[b].empty() || L.XA[b][l] < 0)) || (!xa && L.YA[b].empty())) return -1;
+        if ((xa && (!xa_materialize() || L.XA[b].empty() || L.XA[b][l] < 0)) || (!xa && L.YA[b].empty())) return -1;
         *off = xa ? L.XA[b][l] : L.YA[b][l]; *th = blocks[b].H; *tw = blocks[b].W;
         *tc = xa ? blocks[b].layers[l].cin : cfg.bn_size * cfg.growth; *tld = xa ? (int)round_up(*tc, 8) : *tc;
         return 0;

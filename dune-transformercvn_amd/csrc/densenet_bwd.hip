@@ -231,6 +231,9 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                     const int cin8 = (int)round_up(ls.cin, 8);
                     GemmTnArgs ga{ws + L.ey, mid, mid, ws + L.XA[bi][l], cin8, cin8, M, gw_of(ls.w1), ef.Kp, ws + L.zeros,
                                   reinterpret_cast<float*>(ws + L.slab), kSlabGemmBytes, mid, bias_job};
+                    if (!xa_materialize()) {      // raw concat buffer as the R operand, transformed tile by tile in LDS
+                        ga.R = D; ga.ldr = bg.ld; ga.rsc = sc_of(ls.n1); ga.rsh = sh_of(ls.n1); ga.rsl = data[ls.a1]; ga.Rreal = ls.cin;
+                    }
                     if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<conv1>", st))) return rc;
                 } else if ((rc = conv_wgrad(w, st))) return rc;
             }

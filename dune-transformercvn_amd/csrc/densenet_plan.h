@@ -31,6 +31,8 @@ struct Layout {
     std::vector<long> G, pqD;
 };
 
+bool xa_materialize();      // true unless TCVN_XA_ONTHEFLY is set: keep the activated copy of every 1x1 input in HBM (A/B switch)
+
 struct DenseNetPlan {
     tcvn_densenet_cfg cfg;
     int esz, Hc, Wc, Cf, n_bn = 0;

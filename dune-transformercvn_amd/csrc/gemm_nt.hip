@@ -36,12 +36,16 @@ __device__ __forceinline__ void dma_a(char* smem_base, int buf_off, const bf16* 
     }
 }
 
-template <int EPI, int MAXKS, int ROWS>
+// XF = 1 (forward only): A is the RAW BatchNorm input; every landed A tile is transformed in LDS to prelu(sc*x + sh) before the
+// MFMAs read it (tables in LDS, 4-8 16-B chunks per thread), so the activated copy of the concat buffer is never written to HBM
+template <int EPI, int MAXKS, int ROWS, int XF = 0>
 __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = ROWS * 256;
     float* Cs = reinterpret_cast<float*>(smem + 2 * TILE);                 // [ROWS][CLD]
     double* red = reinterpret_cast<double*>(smem + 2 * TILE);              // [4][128][3] aliases Cs after the last tile
+    float* atab = reinterpret_cast<float*>(smem + 2 * TILE + ROWS * CLD * 4);   // XF: [3][Kt] scale, shift, slope of the A transform
+    const int Kt = (g.K + 7) & ~7;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -82,6 +86,34 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { st1[j] = 0; st2[j] = 0; st3[j] = 0; }
 
+    if (XF) {
+        for (int i = threadIdx.x; i < Kt; i += 256) {
+            const bool ok = i < g.Kreal;
+            atab[i] = ok ? g.asc[i] : 0.f; atab[Kt + i] = ok ? g.ash[i] : 0.f; atab[2 * Kt + i] = ok ? g.asl[i] : 0.f;
+        }
+    }
+    // in-LDS transform of the k-chunk kc held in buffer `buf`: slot s of row r holds source chunk s ^ (r & 15)
+    auto xform = [&](int buf, int kc) {
+#pragma unroll
+        for (int it = 0; it < ROWS * 16 / 256; ++it) {
+            const int idx = tid + 256 * it, row = idx >> 4, slot = idx & 15;
+            const int col = kc * 128 + ((slot ^ (row & 15)) << 3);
+            if (col < Kt) {
+                u16x8* p = reinterpret_cast<u16x8*>(smem + buf + row * 256 + (slot << 4));
+                const u16x8 v = *p;
+                const float4 s0 = *reinterpret_cast<const float4*>(atab + col), s1 = *reinterpret_cast<const float4*>(atab + col + 4);
+                const float4 h0 = *reinterpret_cast<const float4*>(atab + Kt + col), h1 = *reinterpret_cast<const float4*>(atab + Kt + col + 4);
+                const float4 l0 = *reinterpret_cast<const float4*>(atab + 2 * Kt + col), l1 = *reinterpret_cast<const float4*>(atab + 2 * Kt + col + 4);
+                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                const float sl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+                u16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = col + j < g.Kreal ? f2bf(prelu(fmaf(bf2f(v[j]), sc[j], sh[j]), sl[j])) : (bf16)0;
+                *p = o;
+            }
+        }
+    };
     long mt = blockIdx.x;
     if (mt < mtiles) dma_a<ROWS>(smem, 0, A, g.lda, g.K, 0, mt * ROWS, g.M, zeros, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -115,6 +147,10 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
                 if (kc + 1 < nkc) dma_a<ROWS>(smem, (cur ^ 1) * TILE, A, g.lda, g.K, (kc + 1) * 128, mt * ROWS, g.M, zeros, wave, lane);
                 else if (mt + gridDim.x < mtiles) dma_a<ROWS>(smem, (cur ^ 1) * TILE, A, g.lda, g.K, 0, (mt + gridDim.x) * ROWS, g.M, zeros, wave, lane);
                 const int ab = cur * TILE;
+                if (XF) {                       // bare barrier: a __syncthreads() would drain the prefetch just issued
+                    xform(ab, kc);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     if (kc * 8 + ks < ksteps) {
@@ -256,15 +292,17 @@ int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
     if (!gemm_nt_ok(a)) return -2;
     if (a.part != nullptr && a.nblk != gemm_nt_nblk(a)) { fprintf(stderr, "tcvn: gemm_nt nblk mismatch\n"); return -3; }
     const int rows = nt_rows(a);
-    const size_t smem = 2 * rows * 256 + (size_t)rows * CLD * 4;
+    const size_t smem = 2 * rows * 256 + (size_t)rows * CLD * 4 + (a.epi == EPI_FWD && a.asc != nullptr ? 3 * ((a.K + 7) & ~7) * 4 : 0);
     static bool attr = false;
     if (!attr) {
-        const void* fns[6] = {reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128>),
+        const void* fns[8] = {reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128>),
                               reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64>),
                               reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD, 64>),
                               reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD_SMALL, 64>),
                               reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL, 128>),
-                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL_SMALL, 64>)};
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD_POOL, KS_POOL_SMALL, 64>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128, 1>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64, 1>)};
         for (const void* f : fns) TCVN_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
@@ -273,7 +311,10 @@ int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
     const double bytes = (double)a.M * 2.0 * (a.K + (a.epi == EPI_FWD ? (double)a.N : 3.0 * px * a.N));
     ProfScope ps(label, 2.0 * a.M * (double)a.N * a.K, bytes, st);
     const dim3 grid(gemm_nt_nblk(a), cdiv(a.N, 128));
-    if (a.epi == EPI_FWD && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64>), grid, dim3(256), smem, st, a);
+    const bool xf = a.epi == EPI_FWD && a.asc != nullptr;
+    if (xf && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64, 1>), grid, dim3(256), smem, st, a);
+    else if (xf) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128, 1>), grid, dim3(256), smem, st, a);
+    else if (a.epi == EPI_FWD && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64>), grid, dim3(256), smem, st, a);
     else if (a.epi == EPI_FWD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128>), grid, dim3(256), smem, st, a);
     else if (a.epi == EPI_DGRAD && a.Kp <= KS_DGRAD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD_SMALL, 64>), grid, dim3(256), smem, st, a);
     else if (a.epi == EPI_DGRAD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD, 64>), grid, dim3(256), smem, st, a);

@@ -39,6 +39,9 @@ __device__ __forceinline__ void dma_tile(char* smem_base, int buf_off, const bf1
     }
 }
 
+// XF = 1: R is the RAW BatchNorm input; each landed R tile is transformed in LDS to prelu(sc*x + sh) (rows beyond the slice and
+// columns beyond Rreal stay zero), so the weight gradient needs no activated copy of the concat buffer in HBM
+template <int XF>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const GemmTnArgs g, long rows_per_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = ROWS * 256;                               // bytes of one operand tile
@@ -69,6 +72,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const GemmTnArgs g, lon
         achunk[t] = wi * 8 + t * 4 + 2 * chalf + (tp >> 1);
         bchunk[t] = wj * 8 + t * 4 + 2 * chalf + (tp >> 1);
     }
+    float* rtab = reinterpret_cast<float*>(smem + 4 * TILE);               // XF: [3][128] scale, shift, slope of columns j0..j0+127
+    if (XF) {
+        for (int i = tid; i < 128; i += 256) {
+            const bool ok = j0 + i < g.Rreal;
+            rtab[i] = ok ? g.rsc[j0 + i] : 0.f; rtab[128 + i] = ok ? g.rsh[j0 + i] : 0.f; rtab[256 + i] = ok ? g.rsl[j0 + i] : 0.f;
+        }
+    }
+    auto xform = [&](int buf, long m0) {
+#pragma unroll
+        for (int it = 0; it < ROWS * 16 / 256; ++it) {
+            const int idx = tid + 256 * it, row = idx >> 4, slot = idx & 15;
+            const int cl = (slot ^ (row & 15)) << 3;                       // column inside the 128-column tile
+            if (m0 + row < m_end && j0 + cl < g.Rreal) {
+                u16x8* p = reinterpret_cast<u16x8*>(smem + buf + row * 256 + (slot << 4));
+                const u16x8 v = *p;
+                u16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = j0 + cl + j < g.Rreal ? f2bf(prelu(fmaf(bf2f(v[j]), rtab[cl + j], rtab[128 + cl + j]), rtab[256 + cl + j])) : (bf16)0;
+                *p = o;
+            }
+        }
+    };
     if (m_begin < m_end) {
         dma_tile(smem, 0, Lp, g.ldl, g.Li, i0, m_begin, m_end, zeros, wave, lane);
         dma_tile(smem, 2 * TILE, Rp, g.ldr, g.Rj, j0, m_begin, m_end, zeros, wave, lane);
@@ -82,6 +108,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const GemmTnArgs g, lon
             dma_tile(smem, 2 * TILE + (cur ^ 1) * TILE, Rp, g.ldr, g.Rj, j0, m0 + ROWS, m_end, zeros, wave, lane);
         }
         const int lb = cur * TILE, rb = 2 * TILE + cur * TILE;
+        if (XF) {                               // bare barrier: a __syncthreads() would drain the prefetch just issued
+            xform(rb, m0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
 #pragma unroll 2
         for (int ks = 0; ks < ROWS / 16; ++ks) {
             const int row = ks * 16 + 8 * khalf + tq, row2 = row + 4;
@@ -139,13 +169,15 @@ int gemm_tn_bf16(const GemmTnArgs& a, const char* label, hipStream_t st) {
     split = (int)((a.M + rows - 1) / rows);
     static bool attr = false;
     if (!attr) {
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_bf16<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_bf16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     if (a.slab == nullptr || a.Ci <= 0 || a.Ci > a.Li || (long)split * a.Ci * a.ldc * 4 > a.slab_bytes || cdiv(a.ldc, 128) > jt) return -3;
     {
         ProfScope ps(label, 2.0 * a.M * (double)a.Li * a.Rj, (double)a.M * 2.0 * (a.Li + a.Rj), st);
-        hipLaunchKernelGGL(k_gemm_tn_bf16, dim3(jt, it, split), dim3(256), 4 * ROWS * 256, st, a, rows);
+        if (a.rsc != nullptr) hipLaunchKernelGGL(k_gemm_tn_bf16<1>, dim3(jt, it, split), dim3(256), 4 * ROWS * 256 + 3 * 128 * 4, st, a, rows);
+        else hipLaunchKernelGGL(k_gemm_tn_bf16<0>, dim3(jt, it, split), dim3(256), 4 * ROWS * 256, st, a, rows);
         TCVN_LAUNCH_CHECK();
     }
     return slab_reduce2(slab_job(a.slab, split, (long)a.Ci * a.ldc, a.C, 0), a.extra, st);

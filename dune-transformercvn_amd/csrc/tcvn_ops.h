@@ -174,7 +174,8 @@ int slab_reduce2(const SlabJob& a, const SlabJob& b, hipStream_t st);          /
 struct GemmTnArgs { const void* L; long ldl; int Li; const void* R; long ldr; int Rj; long M; float* C; long ldc; const void* zeros;
                     float* slab; long slab_bytes;        // slab: scratch for per-slice partial tiles (no contended atomics)
                     int Ci;                              // rows of C written (<= Li; L columns in [Ci, Li) are zero padding)
-                    SlabJob extra; };                    // optional second reduction folded into this GEMM's slab reduction
+                    SlabJob extra;                       // optional second reduction folded into this GEMM's slab reduction
+                    const float *rsc, *rsh, *rsl; int Rreal; };   // optional: R is raw, transform prelu(rsc*x + rsh, rsl) in LDS
 // dst[i] += sum_s slab[s*count + i]   (deterministic reduction of per-workgroup partial results)
 int slab_reduce(const float* slab, int nslab, long count, float* dst, hipStream_t st, long stride = 0);   // stride 0 = count
 bool gemm_tn_ok(const GemmTnArgs& a);
@@ -189,6 +190,8 @@ struct GemmNtArgs {
     const void* Wfrag; int Kp;               // weights [N][Kp] in MFMA fragment order
     const void* zeros;
     const float* bias; void* Out; long ldo; int n_off;             // EPI_FWD
+    const float *asc, *ash, *asl; int Kreal;                       // EPI_FWD, optional: A is raw, transform prelu(asc*x + ash, asl) in LDS;
+                                                                   // channels >= Kreal are zeroed
     const void* Xin; long ldxin; const float *sc, *sh, *sl;        // EPI_DGRAD*: BatchNorm input + its table
     void* Gout; long ldgo;
     int H, W, Hin, Win;                      // EPI_DGRAD_POOL geometry (rows = pooled pixels H x W of inputs Hin x Win)

@@ -73,7 +73,7 @@ for it in range(reps):
     taps = {"conv0": eng.tap("conv0").clone(), "raw:wk": eng.tap("raw:wk").clone(), "raw:tabs": eng.tap("raw:tabs").clone(),
             "raw:bstat1": eng.tap("raw:bstat1").clone()}
     for l in range(cfg.densenet_structure[0]):
-        for nm in ("xa", "bottleneck", "ya"):
+        for nm in (("xa", "bottleneck", "ya") if not os.environ.get("TCVN_XA_ONTHEFLY") else ("bottleneck", "ya")):
             taps[f"{nm}1.{l}"] = eng.tap(f"{nm}1.{l}").clone()
     taps.update({f"dense{i + 1}": eng.tap(f"dense{i + 1}").clone() for i in range(nb)})
     eng.backward(d_out)
