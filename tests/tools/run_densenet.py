@@ -1,6 +1,6 @@
-"""Run the DenseNet engine alone (profiling aid): python tools/run_densenet.py [n_img] [bf16|fp32] [fwd|fwdbwd] [iters]"""
+"""Run the DenseNet engine alone (profiling aid): python tests/tools/run_densenet.py [n_img] [bf16|fp32] [fwd|fwdbwd] [iters]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dune-transformercvn_amd"), os.path.join(ROOT, "tests")]
 import torch
 from oracle import tcvn_oracle as O

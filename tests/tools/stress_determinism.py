@@ -1,6 +1,6 @@
 """Run the same train-mode bf16 DenseNet forward(+backward) repeatedly; every repetition must be bit-identical."""
 import sys, os, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "dune-transformercvn_amd")]
 import test_densenet_gpu as T
 from oracle import tcvn_oracle as O
