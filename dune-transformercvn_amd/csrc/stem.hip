@@ -4,6 +4,7 @@
 //         dW0[n][ky][kx][c] = sum_hits v[hit][c] * eff0[(y+3-ky)/2, (x+3-kx)/2][n]
 //     touches ~12 output pixels per hit instead of contracting 147 taps for every one of the 28 000 output pixels
 //     (~1.7 GFLOP instead of 135 GFLOP per 288 maps).
+#include <cstdlib>
 #include "tcvn_ops.h"
 #include "prof.h"
 
@@ -139,6 +140,102 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad_sparse(const StemWgradArg
     }
 }
 
+
+
+// Tiled variant (64 channels): a workgroup owns 8 x 32 conv0-output pixels of one map.  The effective gradient of the 5 x 17
+// pooled pixels whose 3x3/2 windows touch the tile is computed ONCE into LDS (fp32); the per-pixel pass then sums its <= 4 windows
+// from LDS instead of re-reading (G, x) of every window from L2 (4 x 256 B per pixel and chunk in k_pool0_bwd_vec).
+constexpr int PB_TH = 8, PB_TW = 32, PB_PH = PB_TH / 2 + 1, PB_PW = PB_TW / 2 + 1;
+__global__ __launch_bounds__(256) void k_pool0_bwd_tile(const Pool0BwdArgs a, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float effs[PB_PH * PB_PW * 64];
+    __shared__ double red[4][8][8][3];
+    const bf16* X = reinterpret_cast<const bf16*>(a.X);
+    const bf16* G = reinterpret_cast<const bf16*>(a.e.G);
+    const bf16* D = reinterpret_cast<const bf16*>(a.e.X);
+    bf16* DU = reinterpret_cast<bf16*>(a.DU);
+    const int tid = threadIdx.x, c8 = tid & 7;
+    float sc[8], sh[8], sl[8], cP[8], cQ[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = a.sc[c8 * 8 + j]; sh[j] = a.sh[c8 * 8 + j]; sl[j] = a.sl[c8 * 8 + j];
+        cP[j] = a.e.P[c8 * 8 + j]; cQ[j] = a.e.Q[c8 * 8 + j];
+    }
+    double s1[8], s2[8], s3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; s3[j] = 0; }
+    const long ntiles = (long)a.n_img * tiles_x * tiles_y;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+        const long img = tile / ((long)tiles_x * tiles_y);
+        const int h0 = ty * PB_TH, w0 = tx * PB_TW, ho0 = h0 / 2 - 1, wo0 = w0 / 2 - 1;
+        __syncthreads();                                                   // previous tile's readers are done with effs
+        for (int i = tid; i < PB_PH * PB_PW * 8; i += 256) {               // eff of the pooled pixels (zero outside the map)
+            const int pp = i >> 3, py = pp / PB_PW, px = pp - py * PB_PW, ho = ho0 + py, wo = wo0 + px;
+            float e8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ho >= 0 && ho < a.Ho && wo >= 0 && wo < a.Wo) {
+                const long mo = (img * a.Ho + ho) * a.Wo + wo;
+                const u16x8 gv = *reinterpret_cast<const u16x8*>(G + mo * a.e.ldg + c8 * 8);
+                const u16x8 dv = *reinterpret_cast<const u16x8*>(D + mo * a.e.ldx + c8 * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e8[j] = bf2f(gv[j]) + cP[j] * bf2f(dv[j]) + cQ[j];
+            }
+            float4* o = reinterpret_cast<float4*>(effs + pp * 64 + c8 * 8);
+            o[0] = make_float4(e8[0], e8[1], e8[2], e8[3]); o[1] = make_float4(e8[4], e8[5], e8[6], e8[7]);
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int k = 0; k < PB_TH * PB_TW / 32; ++k) {
+            const int pi = (tid >> 3) + 32 * k, ly = pi / PB_TW, lx = pi - ly * PB_TW, h = h0 + ly, w = w0 + lx;
+            if (h >= a.Hin || w >= a.Win) continue;
+            // windows containing h: ho = h/2, and h/2 - 1 when h is even (rows 2ho .. 2ho+2); pooled index relative to ho0
+            const int py1 = h / 2 - ho0, px1 = w / 2 - wo0;
+            float dz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                if (dy == 1 && (h & 1)) continue;
+                const int py = py1 - dy;                                   // out-of-map windows hold zeros in effs
+                if (h / 2 - dy >= a.Ho) continue;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    if (dx == 1 && (w & 1)) continue;
+                    if (w / 2 - dx >= a.Wo) continue;
+                    const float4* e4 = reinterpret_cast<const float4*>(effs + (py * PB_PW + px1 - dx) * 64 + c8 * 8);
+                    const float4 x0 = e4[0], x1 = e4[1];
+                    dz[0] += x0.x; dz[1] += x0.y; dz[2] += x0.z; dz[3] += x0.w; dz[4] += x1.x; dz[5] += x1.y; dz[6] += x1.z; dz[7] += x1.w;
+                }
+            }
+            const long p = (img * a.Hin + h) * a.Win + w;
+            const u16x8 xv = *reinterpret_cast<const u16x8*>(X + p * a.C + c8 * 8);
+            u16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float z = dz[j] * (1.0f / 9.0f);
+                const float x = bf2f(xv[j]);
+                const float u = fmaf(x, sc[j], sh[j]);
+                const float du = u > 0.f ? z : sl[j] * z;
+                s1[j] += du; s2[j] += (double)du * x; s3[j] += u > 0.f ? 0.f : z * u;
+                o[j] = f2bf(sc[j] * du);
+            }
+            *reinterpret_cast<u16x8*>(DU + p * a.C + c8 * 8) = o;
+        }
+    }
+    // threads with equal (tid & 7) hold the same channels: fold lanes 8, 16, 32 apart, then the four waves
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); s3[j] += __shfl_xor(s3[j], o); }
+        if (lane < 8) { red[wave][lane][j][0] = s1[j]; red[wave][lane][j][1] = s2[j]; red[wave][lane][j][2] = s3[j]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int ch = tid >> 3, j = tid & 7;
+        double x = 0, y = 0, z = 0;
+        for (int w = 0; w < 4; ++w) { x += red[w][ch][j][0]; y += red[w][ch][j][1]; z += red[w][ch][j][2]; }
+        double* o = a.part + ((long)blockIdx.x * a.C + tid) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // conv0 forward (7x7, stride 2, pad 3, 3 -> 64 channels; reference layers/dense_net.py:112-116) as an implicit GEMM:
@@ -295,6 +392,12 @@ bool pool0_bwd_vec_ok(const Pool0BwdArgs& a) {
 int pool0_bwd_vec(const Pool0BwdArgs& a, hipStream_t st) {
     if (!pool0_bwd_vec_ok(a)) return -2;
     if (a.nblk != pool0_bwd_vec_grid(a.n_img, a.Hin, a.Win)) return -3;
+    static const bool old = getenv("TCVN_POOL0_BWD_FLAT") != nullptr;        // A/B switch
+    if (a.C == 64 && !old) {
+        hipLaunchKernelGGL(k_pool0_bwd_tile, dim3(a.nblk), dim3(256), 0, st, a, cdiv(a.Win, PB_TW), cdiv(a.Hin, PB_TH));
+        TCVN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_pool0_bwd_vec, dim3(a.nblk), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
