@@ -11,18 +11,32 @@ namespace {
 
 // C[i][j] (+)= alpha * sum_k A[i*sai + k*sak] * B[j*sbj + k*sbk] + bias[j]
 __global__ __launch_bounds__(256) void k_sgemm(const SgemmArgs a) {
-    __shared__ float As[16][17], Bs[16][17];
+    // 16 x 16 outputs per workgroup, K in panels of 128: all 16 loads of a thread are in flight together and a panel costs two
+    // barriers (the token-path GEMMs are latency-bound: M = 288 rows, K <= 320 -- 16-wide panels spent 8 HBM round trips per launch)
+    constexpr int KP = 128;
+    __shared__ float As[16][KP + 1], Bs[16][KP + 1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
+    const int jb = blockIdx.x * 16 + ty;
     float acc = 0.f;
-    for (int k0 = 0; k0 < a.K; k0 += 16) {
-        const int ia = blockIdx.y * 16 + ty, ka = k0 + tx;
-        As[ty][tx] = (ia < a.M && ka < a.K) ? a.A[(long)ia * a.sai + (long)ka * a.sak] : 0.f;
-        const int jb = blockIdx.x * 16 + ty, kb = k0 + tx;
-        Bs[ty][tx] = (jb < a.N && kb < a.K) ? a.B[(long)jb * a.sbj + (long)kb * a.sbk] : 0.f;
-        __syncthreads();
+    for (int k0 = 0; k0 < a.K; k0 += KP) {
+        float va[KP / 16], vb[KP / 16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);
+        for (int q = 0; q < KP / 16; ++q) {
+            const int k = k0 + tx + 16 * q;
+            va[q] = (i < a.M && k < a.K) ? a.A[(long)i * a.sai + (long)k * a.sak] : 0.f;
+            vb[q] = (jb < a.N && k < a.K) ? a.B[(long)jb * a.sbj + (long)k * a.sbk] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < KP / 16; ++q) { As[ty][tx + 16 * q] = va[q]; Bs[ty][tx + 16 * q] = vb[q]; }
+        __syncthreads();
+        const int kn = a.K - k0 < KP ? a.K - k0 : KP;
+        if (kn == KP) {
+#pragma unroll 16
+            for (int k = 0; k < KP; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);
+        } else {
+            for (int k = 0; k < kn; ++k) acc = fmaf(As[ty][k], Bs[tx][k], acc);
+        }
         __syncthreads();
     }
     if (i < a.M && j < a.N) {
