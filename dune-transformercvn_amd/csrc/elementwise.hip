@@ -238,6 +238,60 @@ __global__ void k_pack(const PackDesc* descs) {
     }
 }
 
+
+// bf16, 64 channels: one thread per (pooled pixel, 8-channel chunk), nine 16-B loads of the conv0 output, one 16-B store
+__global__ __launch_bounds__(256) void k_pool0_vec64(const Pool0Args a) {
+    __shared__ double red[4][8][8][2];
+    const bf16* X = reinterpret_cast<const bf16*>(a.X);
+    bf16* O = reinterpret_cast<bf16*>(a.Out);
+    const int tid = threadIdx.x, c8 = tid & 7;
+    float sc[8], sh[8], sl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = a.sc[c8 * 8 + j]; sh[j] = a.sh[c8 * 8 + j]; sl[j] = a.sl[c8 * 8 + j]; }
+    double s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; }
+    const long npix = (long)a.n_img * a.Ho * a.Wo;
+    for (long p = (long)blockIdx.x * 32 + (tid >> 3); p < npix; p += (long)gridDim.x * 32) {
+        const int wo = (int)(p % a.Wo);
+        const int ho = (int)((p / a.Wo) % a.Ho);
+        const long img = p / ((long)a.Wo * a.Ho);
+        const bf16* base = X + ((img * a.Hin + 2 * ho) * a.Win + 2 * wo) * 64 + c8 * 8;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const u16x8 v = *reinterpret_cast<const u16x8*>(base + ((long)dy * a.Win + dx) * 64);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += prelu(fmaf(bf2f(v[j]), sc[j], sh[j]), sl[j]);
+            }
+        u16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o[j] = f2bf(acc[j] * (1.0f / 9.0f));
+            const double x = (double)bf2f(o[j]);
+            s1[j] += x; s2[j] += x * x;
+        }
+        *reinterpret_cast<u16x8*>(O + p * a.ldo + c8 * 8) = o;
+    }
+    if (a.part == nullptr) return;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); }
+        if (lane < 8) { red[wave][lane][j][0] = s1[j]; red[wave][lane][j][1] = s2[j]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int ch = tid >> 3, j = tid & 7;
+        double x = 0, y = 0;
+        for (int w = 0; w < 4; ++w) { x += red[w][ch][j][0]; y += red[w][ch][j][1]; }
+        a.part[((long)blockIdx.x * 64 + tid) * 2] = x;
+        a.part[((long)blockIdx.x * 64 + tid) * 2 + 1] = y;
+    }
+}
 }  // namespace
 
 int bn_link(const BnLinkArgs& a, hipStream_t st) {
@@ -272,6 +326,7 @@ int pool0_fwd(const Pool0Args& a, hipStream_t st) {
     const int gx = pool0_grid(a.n_img, a.Ho, a.Wo);
     if (a.part != nullptr && a.nblk != gx) { fprintf(stderr, "tcvn: pool0 nblk mismatch\n"); return -3; }
     if (a.mode == MODE_F32) hipLaunchKernelGGL(k_pool0<float>, dim3(gx), dim3(256), 0, st, a);
+    else if (a.C == 64 && (a.ldo & 7) == 0) hipLaunchKernelGGL(k_pool0_vec64, dim3(gx), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_pool0<bf16>, dim3(gx), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
