@@ -701,19 +701,23 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
         u16x8 ya[2], yb[2];
         load_y(cur, 0, ya);
 
-        f32x16 acc[4];
+        // the 128 positions are multiplied in two halves of 64 (two accumulator tiles live instead of four: the kernel sits at
+        // the 256-register limit of two workgroups per CU); each half is followed by its two 32-row epilogue passes
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int half = 0; half < 2; ++half) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
         if (!(dbg & 2))
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int base = q.halo - ((tap / 3 - 1) * q.Wp + (tap % 3 - 1)) + r;      // source position = p - shift(tap)
+            const int base = q.halo - ((tap / 3 - 1) * q.Wp + (tap % 3 - 1)) + r + half * 64;      // source position = p - shift(tap)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < 2; ++mt) {
                     const int lr = base + mt * 32;
                     const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(smem + off64(lr, 2 * ks + h));
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[tap * 2 + ks], acc[mt], 0, 0, 0);
@@ -723,12 +727,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
         // epilogue, four passes of 32 rows through the fp32 C tile: u = sc*y + sh ; dU = dA * prelu'(u) ; DU = sc*dU ;
         // sums (dU, dU*y, dA*min(u,0)) per channel
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pp = 0; pp < 2; ++pp) {
+            const int pass = half * 2 + pp;
             u16x8 (&yc)[2] = (pass & 1) ? yb : ya;
             u16x8 (&yn)[2] = (pass & 1) ? ya : yb;
             if (pass < 3) load_y(cur, pass + 1, yn);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) Cs[((k & 3) + 8 * (k >> 2) + 4 * h) * CLD3 + wave * 32 + r] = acc[pass][k];
+            for (int k = 0; k < 16; ++k) Cs[((k & 3) + 8 * (k >> 2) + 4 * h) * CLD3 + wave * 32 + r] = acc[pp][k];
             lds_barrier();
             float esc[8], esh[8], esl[8];
 #pragma unroll
@@ -762,6 +767,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
             }
             lds_barrier();
         }
+        }   // half
     }
     // reduce the 16 row groups: 4 per wave by shuffles (lane bits 4, 5), then across waves through LDS
     __syncthreads();
