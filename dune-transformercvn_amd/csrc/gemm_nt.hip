@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
                             const int ho = rem / g.W, wo = rem - ho * g.W;
                             p00 = (img * g.Hin + 2 * ho) * g.Win + 2 * wo;
                         }
-#pragma unroll
+#pragma unroll 1
                         for (int t = 0; t < 4; ++t) {
                             if (t < npx) {
                                 const long px = EPI == EPI_DGRAD_POOL ? p00 + (t >> 1) * g.Win + (t & 1) : m;
