@@ -224,6 +224,42 @@ torch.save(dict(out=out, taps=taps, grads=grads), {('/tmp/tcvn_generic_' + name 
     assert e_out < 5e-3 and e_tap < 1e-2 and median < 5e-2 and worst < 0.5
 
 
+def test_bf16_fallback_variants_match_default_variants():
+    """The strip forward kernel (TCVN_DBG=32: used when a map is wider than the 512-row LDS ring allows) and the flat pool0
+    backward (TCVN_POOL0_BWD_FLAT) against the default ring / tiled variants in a separate process: same arithmetic, different
+    staging, so the forward must agree to bf16-rounding level."""
+    import subprocess, sys, os
+    cfg, over, batch, g = _mid_case()
+    cfg = train_cfg(over)
+    sd = O.fill_state(cfg, int(g["weight_seed"]))
+    n_img = int(batch[7].sum())
+    d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
+    out, taps, grads = _run_bf16(cfg, sd, batch, True, d_out)
+    code = f"""
+import sys, torch
+sys.path[:0] = {sys.path!r}
+import test_densenet_gpu as T
+from oracle import tcvn_oracle as O
+from golden_utils import train_cfg
+cfg, over, batch, g = T._mid_case()
+cfg = train_cfg(over)
+sd = O.fill_state(cfg, int(g['weight_seed']))
+n_img = int(batch[7].sum())
+d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
+out, taps, grads = T._run_bf16(cfg, sd, batch, True, d_out)
+torch.save(dict(out=out, taps=taps, grads=grads), '/tmp/tcvn_fallback_mid.pt')
+"""
+    env = dict(os.environ, TCVN_DBG="32", TCVN_POOL0_BWD_FLAT="1")
+    subprocess.check_call([sys.executable, "-c", code], env=env)
+    ref = torch.load("/tmp/tcvn_fallback_mid.pt")
+    e_out = ((out - ref["out"]).norm() / ref["out"].norm()).item()
+    e_tap = max(((taps[k] - ref["taps"][k]).norm() / ref["taps"][k].norm()).item() for k in taps)
+    k0 = "features.conv0.weight"
+    e_w0 = ((grads[k0] - ref["grads"][k0]).norm() / ref["grads"][k0].norm()).item()
+    print("fallback vs default: out", e_out, "taps", e_tap, "conv0.weight grad", e_w0)
+    assert e_out < 5e-3 and e_tap < 1e-2 and e_w0 < 0.2
+
+
 @pytest.mark.parametrize("name", ["small_b3", "mid", "tutorial_b2p4"])
 def test_densenet_bf16_backward_tracks_fp64_oracle(name):
     """Every bf16 gradient tensor must point the same way as the fp64 oracle gradient (cosine) and have its size: a tiling /
