@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--prongs", type=int, default=8)
+    ap.add_argument("--dropout", type=float, default=None, help="override options.dropout (experiments only; the metric uses the file's 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--dump-records", default="", help="write every profiled launch (name, ms, flops) to this JSON file")
@@ -120,6 +121,8 @@ def main():
     opt = Options.load(os.path.join(PKG, "option_files", "tutorial_densenet_synthetic.json"))
     opt.batch_size, opt.num_gpu, opt.hip_precision, opt.seed = args.batch, world, args.precision, 1234 + rank
     opt.training_file = f"synthetic:64:{args.prongs}"
+    if args.dropout is not None:
+        opt.dropout = args.dropout
     torch.manual_seed(0)                                            # identical random-init weights on every rank
     model = NeutrinoFullDenseTrainer(opt).to(dev)
     model.train()
