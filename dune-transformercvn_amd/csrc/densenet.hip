@@ -95,6 +95,19 @@ DenseNetPlan::DenseNetPlan(const tcvn_densenet_cfg& c) : cfg(c) {
 DenseNetPlan::~DenseNetPlan() {
     if (d_desc) (void)hipFree(d_desc);
     if (d_undesc) (void)hipFree(d_undesc);
+    if (side_st) {
+        (void)hipStreamSynchronize(side_st);
+        (void)hipStreamDestroy(side_st);
+        (void)hipEventDestroy(ev_fork_a); (void)hipEventDestroy(ev_fork_b); (void)hipEventDestroy(ev_done[0]);
+        (void)hipEventDestroy(ev_done[1]); (void)hipEventDestroy(ev_drain);
+    }
+}
+int DenseNetPlan::ensure_side() {
+    if (side_st) return 0;
+    TCVN_CHECK(hipStreamCreateWithFlags(&side_st, hipStreamNonBlocking));
+    hipEvent_t* evs[5] = {&ev_fork_a, &ev_fork_b, &ev_done[0], &ev_done[1], &ev_drain};
+    for (hipEvent_t* e : evs) TCVN_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <vector>
 
+#include <cstdlib>
 #include "densenet_plan.h"
 #include "tcvn_ops.h"
 #include "tcvn_rows.h"
@@ -40,6 +41,7 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     L.zero_end = b.off;
     L.du = b.take(maxY * esz);
     L.ey = b.take(maxY * esz);
+    L.ey2 = b.take(maxY * esz);                    // second EY buffer: the weight-gradient stream may still read the previous one
     L.slab = b.take(kSlabBytes);
     L.pqY = b.take((long)mid * 8);
     L.du0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
@@ -62,6 +64,23 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
     int rc;
     const int mode = cfg.mode, g = cfg.growth, mid = cfg.bn_size * cfg.growth;
     const uint64_t seed = last_seed;
+    // Weight gradients (3x3 and 1x1, with their slab reductions) do not feed the data-gradient chain: in bf16 mode they run on a
+    // side stream beside it.  Shared state: the slab (side stream only between drains), EY (double buffered, released by
+    // ev_done), the bias column-sum partials (two halves of the slab tail).  TCVN_BWD_SERIAL=1 keeps everything on `st`.
+    static const bool serial_env = getenv("TCVN_BWD_SERIAL") != nullptr;
+    const bool side_on = fast3x3 && !serial_env;
+    if (side_on && (rc = ensure_side())) return rc;
+    int seq = 0;                                   // parity of the EY buffer / tail half; reset by drain()
+    bool side_busy = false;
+    auto drain = [&]() -> int {                    // `st` waits for everything enqueued on the side stream
+        if (side_on && side_busy) {
+            TCVN_CHECK(hipEventRecord(ev_drain, side_st));
+            TCVN_CHECK(hipStreamWaitEvent(st, ev_drain, 0));
+            side_busy = false;
+        }
+        seq = 0;
+        return 0;
+    };
     float* tabs = reinterpret_cast<float*>(ws + L.tabs);
     auto sc_of = [&](const BnSlots& s) { return tabs + tab_off(s); };
     auto sh_of = [&](const BnSlots& s) { return tabs + tab_off(s) + round_up(s.C, 8); };
@@ -152,6 +171,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             w.fa.K = bg.Ctot; w.fa.Kp = ef.Kp; w.fa.C = bg.Ctot; w.fa.H = nb.H; w.fa.W = nb.W; w.fa.Hin = bg.H; w.fa.Win = bg.W;
             w.fa.sc = sc_of(bg.tn); w.fa.sh = sh_of(bg.tn); w.fa.sl = data[bg.ta];
             const int Nt8 = (int)round_up(Nt, 8);
+            if ((rc = drain())) return rc;            // the transition uses EY and the slab on `st`
             if (L.XP[bi] >= 0) {
                 // materialise the output gradient once (+ bias gradient), then dW = ET^T x XP on the TN GEMM
                 SlabJob bias_job{};
@@ -203,7 +223,13 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                     w.nfast = 1; w.fa.Aact = ws + L.YA[bi][l]; w.fa.zeros = ws + L.zeros;
                     w.slab = reinterpret_cast<float*>(ws + L.slab); w.slab_bytes = kSlabBytes;
                 }
-                if ((rc = conv_wgrad(w, st))) return rc;
+                const bool par = side_on && L.XA[bi][l] >= 0;
+                if (par) {                    // G slice, its (P, Q) and the materialised YA are final: fork
+                    TCVN_CHECK(hipEventRecord(ev_fork_a, st));
+                    TCVN_CHECK(hipStreamWaitEvent(side_st, ev_fork_a, 0));
+                    side_busy = true;
+                }
+                if ((rc = conv_wgrad(w, par ? side_st : st))) return rc;
             }
             {   // conv2 data gradient -> DU (= sc2 * dU2) + norm2 partials
                 const WkEntry& et = wk_find(ls.w2, 1);
@@ -225,27 +251,38 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 w.fa.Kp = ef.Kp; w.fa.C = ls.cin; w.fa.H = bg.H; w.fa.W = bg.W;
                 w.fa.sc = sc_of(ls.n1); w.fa.sh = sh_of(ls.n1); w.fa.sl = data[ls.a1];
                 if (L.XA[bi][l] >= 0) {
+                    const bool par = side_on;
+                    char* EY = ws + ((par && (seq & 1)) ? L.ey2 : L.ey);
+                    float* tail = reinterpret_cast<float*>(ws + L.slab + kSlabGemmBytes + ((par && (seq & 1)) ? (kSlabBytes - kSlabGemmBytes) / 2 : 0));
+                    if (par && seq >= 2) TCVN_CHECK(hipStreamWaitEvent(st, ev_done[seq & 1], 0));   // that EY buffer / tail half is free again
                     SlabJob bias_job{};     // bias column sums: reduced together with the weight-gradient slab below
-                    EffMatArgs em{e1, M, ws + L.ey, mid, grad[ls.b1], reinterpret_cast<float*>(ws + L.slab + kSlabGemmBytes), &bias_job};
+                    EffMatArgs em{e1, M, EY, mid, grad[ls.b1], tail, &bias_job};
                     if ((rc = eff_materialize_bf16(em, st))) return rc;
+                    if (par) {
+                        TCVN_CHECK(hipEventRecord(ev_fork_b, st));
+                        TCVN_CHECK(hipStreamWaitEvent(side_st, ev_fork_b, 0));
+                        side_busy = true;
+                    }
                     const int cin8 = (int)round_up(ls.cin, 8);
-                    GemmTnArgs ga{ws + L.ey, mid, mid, ws + L.XA[bi][l], cin8, cin8, M, gw_of(ls.w1), ef.Kp, ws + L.zeros,
+                    GemmTnArgs ga{EY, mid, mid, ws + L.XA[bi][l], cin8, cin8, M, gw_of(ls.w1), ef.Kp, ws + L.zeros,
                                   reinterpret_cast<float*>(ws + L.slab), kSlabGemmBytes, mid, bias_job};
                     if (!xa_materialize()) {      // raw concat buffer as the R operand, transformed tile by tile in LDS
                         ga.R = D; ga.ldr = bg.ld; ga.rsc = sc_of(ls.n1); ga.rsh = sh_of(ls.n1); ga.rsl = data[ls.a1]; ga.Rreal = ls.cin;
                     }
-                    if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<conv1>", st))) return rc;
+                    if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<conv1>", par ? side_st : st))) return rc;
+                    if (par) TCVN_CHECK(hipEventRecord(ev_done[seq & 1], side_st));
                 } else if ((rc = conv_wgrad(w, st))) return rc;
             }
             if (L.XA[bi][l] >= 0) {   // conv1 data gradient on the NT GEMM (A = EY)
                 const WkEntry& etf = wk_find(ls.w1, 1, 1);
                 GemmNtArgs ga{};
-                ga.epi = EPI_DGRAD; ga.A = ws + L.ey; ga.lda = mid; ga.K = mid; ga.M = M; ga.N = ls.cin;
+                ga.epi = EPI_DGRAD; ga.A = ws + ((side_on && (seq & 1)) ? L.ey2 : L.ey); ga.lda = mid; ga.K = mid; ga.M = M; ga.N = ls.cin;
                 ga.Wfrag = ws + L.wk + etf.off; ga.Kp = etf.Kp; ga.zeros = ws + L.zeros;
                 ga.Xin = D; ga.ldxin = bg.ld; ga.sc = sc_of(ls.n1); ga.sh = sh_of(ls.n1); ga.sl = data[ls.a1];
                 ga.Gout = G; ga.ldgo = bg.ld; ga.part = part; ga.nblk = gemm_nt_nblk(ga);
                 if ((rc = gemm_nt_bf16(ga, "k_gemm_nt_bf16<dgrad1x1>", st))) return rc;
                 if ((rc = bwd_link(ls.n1, ga.nblk, bstatD, M, P, Q, 1, ls.a1))) return rc;
+                ++seq;
             } else {   // conv1 data gradient -> G[:, 0:cin] += sc1 * dU1, norm1 partials
                 const WkEntry& et = wk_find(ls.w1, 1);
                 ConvDgradArgs d{};
@@ -259,6 +296,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
     }
 
     // ---- stem: AvgPool0 - PReLU0 - BN0 - conv0 ----
+    if ((rc = drain())) return rc;                // the stem weight gradient uses the slab; k_unpack reads every weight gradient
     {
         const BlockGeom& b0 = blocks[0];
         float* P = reinterpret_cast<float*>(ws + L.pqD[0]);

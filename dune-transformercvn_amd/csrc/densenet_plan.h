@@ -23,7 +23,7 @@ struct Layout {
     long img, c0, bstat0, part, tabs, F, Z, head_stat, wk, fwd_end, total;
     std::vector<long> D, bstatD;
     std::vector<std::vector<long>> Y, bstatY, YA;     // YA: activated bf16 copies of Y (bf16 mode)
-    long zeros, ey, slab;
+    long zeros, ey, ey2, slab;
     std::vector<std::vector<long>> XA;   // activated bf16 copies of the 1x1-conv inputs (per layer, -1 if absent)
     std::vector<long> XP;                // pooled activated transition inputs (-1 if absent)
     // backward
@@ -51,6 +51,9 @@ struct DenseNetPlan {
     char* desc_ws = nullptr; long desc_total = 0; int n_pack = 0, n_bneval = 0;
     uint64_t last_seed = 0; int last_n = 0;
     const int32_t* last_coords = nullptr; long last_nnz = 0;     // COO list of the last forward (sparse stem weight gradient)
+    // weight-gradient side stream of backward (3x3 and 1x1 weight gradients run beside the data-gradient chain)
+    hipStream_t side_st = nullptr; hipEvent_t ev_fork_a = nullptr, ev_fork_b = nullptr, ev_done[2] = {nullptr, nullptr}, ev_drain = nullptr;
+    int ensure_side();
     char* d_undesc = nullptr; std::vector<char> h_undesc; char* undesc_ws = nullptr; long undesc_total = 0; int n_unpack = 0;
 
     explicit DenseNetPlan(const tcvn_densenet_cfg& c);

@@ -64,6 +64,7 @@ def analyse(first, cur):
 
 first = None
 nbad = 0
+worst_grad = [0.0, ""]
 for it in range(reps):
     for gr in grads.values():
         gr.zero_()
@@ -107,6 +108,10 @@ for it in range(reps):
             idx = (d > 0).nonzero()
             if k.startswith("g:") or k.startswith("raw:") or not (k == "dense1" or k == "xa1.1"):
                 nbad += 1
+                if k.startswith("g:"):              # atomics reorder fp32 sums (~1e-6); anything larger would be a race
+                    rel = (d.max() / first[k].float().abs().max().clamp_min(1e-20)).item()
+                    if rel > worst_grad[0]:
+                        worst_grad[0], worst_grad[1] = rel, f"{k} rep {it}"
                 continue
             print("rep", it, "tensor", k, "shape", tuple(v.shape), "differs in", len(idx), "elements; first", idx[:6].tolist(),
                   "max diff", d.max().item(), flush=True)
@@ -124,4 +129,4 @@ for it in range(reps):
                         print("   flat pixel ids", flat[:64].tolist())
             if k.startswith("dense2") or k == "out":
                 break
-print("repetitions", reps, "mismatching tensors", nbad)
+print("repetitions", reps, "mismatching tensors", nbad, "worst gradient run-to-run difference (max-norm, relative)", worst_grad)
