@@ -550,6 +550,7 @@ struct tcvn_densenet { DenseNetPlan plan; explicit tcvn_densenet(const tcvn_dens
 extern "C" {
 
 int tcvn_version(void) { return 1; }
+void tcvn_backward_overlap(int on) { tcvn::set_backward_overlap(on); }
 
 int tcvn_densenet_create(const tcvn_densenet_cfg* cfg, tcvn_densenet** out) {
     if (!cfg || !out || cfg->n_blocks < 1 || cfg->n_blocks > 8) return -1;

@@ -11,6 +11,13 @@
 
 using namespace tcvn;
 
+// tcvn_backward_overlap(): off by default.  Measured on MI355X (B=32 x 8 prongs, 3 alternating runs each): 27.16 ms with the
+// weight gradients on the side stream vs 27.43 ms without (1 %); the overlapped kernels then share the CUs, which doubles the
+// per-launch times a profiler sees for them -- not worth it while kernels are still being tuned one by one.
+static int g_backward_overlap = 0;
+bool tcvn::backward_overlap_enabled() { return g_backward_overlap != 0; }
+void tcvn::set_backward_overlap(int on) { g_backward_overlap = on; }
+
 namespace {
 constexpr float kEps = 1e-5f;
 constexpr long kSlabBytes = 48L << 20;      // per-workgroup partial weight gradients (<= 256 x 147 KB) and column sums
@@ -68,7 +75,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
     // side stream beside it.  Shared state: the slab (side stream only between drains), EY (double buffered, released by
     // ev_done), the bias column-sum partials (two halves of the slab tail).  TCVN_BWD_SERIAL=1 keeps everything on `st`.
     static const bool serial_env = getenv("TCVN_BWD_SERIAL") != nullptr;
-    const bool side_on = fast3x3 && !serial_env;
+    const bool side_on = fast3x3 && !serial_env && backward_overlap_enabled();
     if (side_on && (rc = ensure_side())) return rc;
     int seq = 0;                                   // parity of the EY buffer / tail half; reset by drain()
     bool side_busy = false;

@@ -31,6 +31,8 @@ struct Layout {
     std::vector<long> G, pqD;
 };
 
+bool backward_overlap_enabled();
+void set_backward_overlap(int on);
 bool xa_materialize();      // true unless TCVN_XA_ONTHEFLY is set: keep the activated copy of every 1x1 input in HBM (A/B switch)
 
 struct DenseNetPlan {

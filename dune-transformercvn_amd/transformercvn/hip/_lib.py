@@ -68,6 +68,7 @@ def _load():
     sig("tcvn_focal_loss", i32, vp, vp, i32, i32, f32, f32, vp, vp, vp)
     sig("tcvn_grad_sumsq", i32, vp, i64, vp, i32, vp, vp)
     sig("tcvn_adamw_step", i32, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, f32, vp)
+    sig("tcvn_backward_overlap", None, i32)
     sig("tcvn_profile_enable", None, i32)
     sig("tcvn_profile_filter", None, C.c_char_p)
     sig("tcvn_profile_reset", None)
@@ -88,7 +89,7 @@ def profile_records():
 
 
 EXPORTS = [
-    "tcvn_grad_sumsq", "tcvn_adamw_step", "tcvn_profile_enable", "tcvn_profile_filter", "tcvn_profile_reset", "tcvn_profile_count", "tcvn_profile_get",
+    "tcvn_grad_sumsq", "tcvn_adamw_step", "tcvn_backward_overlap", "tcvn_profile_enable", "tcvn_profile_filter", "tcvn_profile_reset", "tcvn_profile_count", "tcvn_profile_get",
     "tcvn_focal_loss",
     "tcvn_version", "tcvn_densenet_create", "tcvn_densenet_destroy", "tcvn_densenet_num_slots", "tcvn_densenet_slot",
     "tcvn_densenet_bind", "tcvn_densenet_workspace_bytes", "tcvn_densenet_forward", "tcvn_densenet_backward",

@@ -146,6 +146,10 @@ int tcvn_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
  * 2*M*N*K of that launch and bytes its algorithmic HBM traffic (operands once, results once).  Off by default; with a
  * filter set only the matching launches pay for their two events, which is cheap enough for the timed region.
  * --------------------------------------------------------------------------------------------------------------- */
+/* Optional: backward runs the 3x3 / 1x1 weight-gradient kernels on a plan-owned side stream beside the data-gradient chain
+ * (double-buffered EY, event-released).  Off by default: +1 % on MI355X, but per-kernel timings of the overlapped kernels
+ * inflate. */
+void tcvn_backward_overlap(int on);
 void tcvn_profile_enable(int on);
 void tcvn_profile_filter(const char* label_substring); /* NULL or "" = every launch; else only matching kernel labels */
 void tcvn_profile_reset(void);

@@ -284,3 +284,28 @@ def test_densenet_bf16_backward_tracks_fp64_oracle(name):
             low.append((k, round(cos.item(), 4), round(ratio, 3)))
     print(name, "tensors off", low[:10])
     assert not low, low[:10]
+
+
+def test_backward_side_stream_option_gives_the_same_gradients():
+    """tcvn_backward_overlap(1): weight gradients on a plan-owned side stream (double-buffered EY).  Same kernels, same inputs:
+    gradients must agree with the serial schedule to atomics-reordering level."""
+    from transformercvn.hip._lib import lib
+    cfg, over, batch, g = load_case("tutorial_b2p4")
+    cfg = train_cfg(over)
+    sd = O.fill_state(cfg, int(g["weight_seed"]))
+    n_img = int(batch[7].sum())
+    d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
+    out0, _, g0 = _run_bf16(cfg, sd, batch, True, d_out)
+    lib.tcvn_backward_overlap(1)
+    try:
+        out1, _, g1 = _run_bf16(cfg, sd, batch, True, d_out)
+    finally:
+        lib.tcvn_backward_overlap(0)
+    assert torch.equal(out0, out1)
+    worst = 0.0
+    for k in g0:
+        scale = g0[k].abs().max().item()
+        if scale > 0:
+            worst = max(worst, (g0[k] - g1[k]).abs().max().item() / scale)
+    print("serial vs side-stream backward: worst relative gradient difference", worst)
+    assert worst < 1e-3
