@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_bf16(const ConvFwdArgs g
     int cur = 0, ts = 0;                                         // image buffer / table slot of the current tile
     for (int t = lb; t < ntiles; t += nb, cur ^= 1, ts = ts == 2 ? 0 : ts + 1) {
         const int tn = ts == 2 ? 0 : ts + 1, tnn = tn == 2 ? 0 : tn + 1;
-        if (t + nb < ntiles && !(g.dbg & 1))                     // prefetch the next tile's image under this tile's MFMAs
+        if (t + nb < ntiles && !TCVN_DBG_BIT(g.dbg, 1))                     // prefetch the next tile's image under this tile's MFMAs
             dma_image(smem, (cur ^ 1) * img_bytes, YA, zeros, tbl + tn * nrows4, nrows4, wave, lane);
         f32x16 acc;
 #pragma unroll
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_bf16(const ConvFwdArgs g
             for (int ks = 0; ks < 8; ++ks)
                 af[0][ks] = *reinterpret_cast<const bf16x8_t*>(smem + image + lr * 256 + (((2 * ks + h) ^ (lr & 15)) << 4));
         }
-        if (!(g.dbg & 2))
+        if (!TCVN_DBG_BIT(g.dbg, 2))
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             if (tap + 1 < 9) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_bf16(const ConvFwdArgs g
         for (int e = 0; e < 16; ++e) {
             const int lp = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             const int m = px[lp];
-            if (m >= 0 && nok && !(g.dbg & 4)) {
+            if (m >= 0 && nok && !TCVN_DBG_BIT(g.dbg, 4)) {
                 float v = acc[e] + bias;
                 if (drop) {
                     if ((m >> 1) != cur_grp) { cur_grp = m >> 1; bits = drop_bits(dkey, m, r, g.N); }
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_ring_bf16(const ConvFwdA
     __syncthreads();
     for (int t = t0; t < t1; ++t) {
         const int k128 = (t - t0) * TP;                          // row of this tile's first image row
-        if (t + 1 < t1 && !(g.dbg & 1)) dma_rows(nrows4 + k128, TP);     // the next tile's 128 new rows, under this tile's MFMAs
+        if (t + 1 < t1 && !TCVN_DBG_BIT(g.dbg, 1)) dma_rows(nrows4 + k128, TP);     // the next tile's 128 new rows, under this tile's MFMAs
         // two accumulator chains (even / odd k-steps): a dependent MFMA chain issues one MFMA per ~54 cycles, two independent
         // chains keep the matrix pipe at its 32-cycle cadence
         f32x16 acc, acc2;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_ring_bf16(const ConvFwdA
             for (int ks = 0; ks < 8; ++ks)
                 af[0][ks] = *reinterpret_cast<const bf16x8_t*>(smem + lr * 256 + (((2 * ks + h) ^ (lr & 15)) << 4));
         }
-        if (!(g.dbg & 2))
+        if (!TCVN_DBG_BIT(g.dbg, 2))
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             if (tap + 1 < 9) {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_ring_bf16(const ConvFwdA
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = mrow[e];
-            if (m >= 0 && nok && !(g.dbg & 4)) {
+            if (m >= 0 && nok && !TCVN_DBG_BIT(g.dbg, 4)) {
                 float v = acc[e] + acc2[e] + bias;
                 if (drop) {
                     if ((m >> 1) != cur_grp) { cur_grp = m >> 1; bits = drop_bits(dkey, m, r, g.N); }
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
         for (int rr = er0; rr < nr; rr += 64) {
             const int m = tbl[cur * nr + rr];
             u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (m >= 0 && !(dbg & 8)) {
+            if (m >= 0 && !TCVN_DBG_BIT(dbg, 8)) {
                 const u16x8 gv = *reinterpret_cast<const u16x8*>(smem + o_rg + rr * 64 + ec * 16);
                 const u16x8 xv = *reinterpret_cast<const u16x8*>(smem + o_rd + rr * 64 + ec * 16);
 #pragma unroll
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
-        if (!(dbg & 2))
+        if (!TCVN_DBG_BIT(dbg, 2))
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int base = q.halo - ((tap / 3 - 1) * q.Wp + (tap % 3 - 1)) + r + half * 64;      // source position = p - shift(tap)
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
             for (int i = 0; i < 2; ++i) {
                 const int rr = e_r0 + 16 * i;
                 const int m = tbl[cur * nr + q.halo + pass * 32 + rr];
-                if (m >= 0 && !(dbg & 4)) {
+                if (m >= 0 && !TCVN_DBG_BIT(dbg, 4)) {
                     const float4 ca = *reinterpret_cast<const float4*>(Cs + rr * CLD3 + e_c8 * 8);
                     const float4 cc = *reinterpret_cast<const float4*>(Cs + rr * CLD3 + e_c8 * 8 + 4);
                     const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cc.x, cc.y, cc.z, cc.w};
@@ -803,8 +803,8 @@ int tile_grid2(long ntiles) {           // two workgroups per CU
 size_t wgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return 2 * r4 * 256 + 2 * TP * 64 + 3 * r4 * 4; }
 
 int tile_grid(long ntiles) {            // one persistent workgroup per CU
-    static const int dbg = getenv("TCVN_DBG") ? atoi(getenv("TCVN_DBG")) : 0;
-    if (dbg & 16) return (int)ntiles;                 // debug: one tile per workgroup
+    [[maybe_unused]] static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
+    if (TCVN_DBG_BIT(dbg, 16)) return (int)ntiles;                 // debug: one tile per workgroup
     if (ntiles >= 256) return 256;
     if (ntiles >= 8) return (int)(ntiles / 8 * 8);
     return (int)ntiles;
@@ -814,7 +814,7 @@ int tile_grid(long ntiles) {            // one persistent workgroup per CU
 
 // n_img is recovered from M = n*H*W
 static bool tile_disabled() {
-    static const bool off = getenv("TCVN_DISABLE_TILE") != nullptr;      // validation switch: force the generic kernels
+    static const bool off = TCVN_KNOB_SET("TCVN_DISABLE_TILE");      // validation switch: force the generic kernels
     return off;
 }
 
@@ -847,9 +847,9 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
     }
     ProfScope ps("k_conv3x3_fwd_bf16", 2.0 * a.M * (double)a.N * a.K, (double)a.M * 2.0 * (a.C + a.N), st);   // read 128 ch, write N ch
     ConvFwdArgs b = a;
-    static const int dbg = getenv("TCVN_DBG") ? atoi(getenv("TCVN_DBG")) : 0;
+    static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
     b.dbg = dbg;
-    if (((q.rows() + 3) & ~3) + TP <= RING && !(dbg & 32)) {       // consecutive tiles per workgroup, ring image (TCVN_DBG=32: strips)
+    if (((q.rows() + 3) & ~3) + TP <= RING && !TCVN_DBG_BIT(dbg, 32)) {       // consecutive tiles per workgroup, ring image (TCVN_DBG=32: strips)
         static bool attr2 = false;
         if (!attr2) {
             TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_fwd_ring_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -860,7 +860,7 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
         TCVN_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(k_conv3x3_fwd_bf16, dim3(nb), dim3(256), smem, st, b, n_img, ntiles, (nb >= 8 && nb % 8 == 0 && !(dbg & 8)) ? 1 : 0);
+    hipLaunchKernelGGL(k_conv3x3_fwd_bf16, dim3(nb), dim3(256), smem, st, b, n_img, ntiles, (nb >= 8 && nb % 8 == 0 && !TCVN_DBG_BIT(dbg, 8)) ? 1 : 0);
     TCVN_LAUNCH_CHECK();
     return 0;
 }
@@ -933,7 +933,7 @@ int conv3x3_dgrad_tile(const ConvDgradArgs& a, hipStream_t st) {
             TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_dgrad2_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             attr = true;
         }
-        static const int dbgd = getenv("TCVN_DBG") ? atoi(getenv("TCVN_DBG")) : 0;
+        static const int dbgd = TCVN_KNOB_INT("TCVN_DBG");
         hipLaunchKernelGGL(k_conv3x3_dgrad2_bf16, dim3(nb), dim3(256), dgrad2_smem(q), st, a, n_img, ntiles, (nb >= 8 && nb % 8 == 0) ? 1 : 0, dbgd);
         TCVN_LAUNCH_CHECK();
         return 0;

@@ -210,7 +210,7 @@ bool DenseNetPlan::fast1_ok(int cin) const {
     return cfg.mode == MODE_BF16 && conv3x3_tile_enabled() && mid % 8 == 0 && mid <= 256 && round_up(cin, 32) <= 640;
 }
 bool tcvn::xa_materialize() {
-    static const bool on = getenv("TCVN_XA_ONTHEFLY") == nullptr;   // default: write prelu(bn1(x)) to HBM once per layer.  A/B on
+    static const bool on = !TCVN_KNOB_SET("TCVN_XA_ONTHEFLY");   // default: write prelu(bn1(x)) to HBM once per layer.  A/B on
     // MI355X (B=32 x 8 prongs): transforming the raw tile in LDS inside the two GEMMs instead saves the copy (2.4 GB, 1.5 ms of
     // k_act_bf16) but costs more than it saves at one or two waves per SIMD: fwd1x1 2.2 -> 4.8 ms, dW1 2.0 -> 3.0 ms, step 29.3 -> 30.7 ms
     return on;
@@ -505,6 +505,7 @@ int DenseNetPlan::tap(int n, const char* name, long* off, int* tn, int* th, int*
     layout(n, false, L);
     std::string s(name);
     *tn = n; *tes = esz;
+    if (s == "img") { *off = L.img; *th = cfg.H; *tw = cfg.W; *tc = cfg.in_ch; *tld = cfg.in_ch; return 0; }
     if (s == "conv0") { *off = L.c0; *th = Hc; *tw = Wc; *tc = cfg.init_ch; *tld = cfg.init_ch; return 0; }
     if (s == "condense") { *off = L.F; *th = 1; *tw = 1; *tc = Cf; *tld = Cf; *tes = 4; return 0; }
     if (s == "raw:wk") { *tn = *th = *tw = 1; *off = L.wk; *tc = *tld = (int)(wk_bytes() / esz); return 0; }

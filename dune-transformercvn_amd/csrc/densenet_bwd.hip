@@ -74,7 +74,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
     // Weight gradients (3x3 and 1x1, with their slab reductions) do not feed the data-gradient chain: in bf16 mode they run on a
     // side stream beside it.  Shared state: the slab (side stream only between drains), EY (double buffered, released by
     // ev_done), the bias column-sum partials (two halves of the slab tail).  TCVN_BWD_SERIAL=1 keeps everything on `st`.
-    static const bool serial_env = getenv("TCVN_BWD_SERIAL") != nullptr;
+    static const bool serial_env = TCVN_KNOB_SET("TCVN_BWD_SERIAL");
     const bool side_on = fast3x3 && !serial_env && backward_overlap_enabled();
     if (side_on && (rc = ensure_side())) return rc;
     int seq = 0;                                   // parity of the EY buffer / tail half; reset by drain()

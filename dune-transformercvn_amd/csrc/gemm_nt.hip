@@ -306,9 +306,11 @@ int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
         for (const void* f : fns) TCVN_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    // algorithmic HBM bytes: A once; FWD writes N channels; the data-gradient epilogues read x and read+write G (4 pixels per row when pooled)
+    // algorithmic HBM bytes, SURVEY 8(d) strict (operands once, results once): A once; FWD writes N channels; the data-gradient
+    // epilogues read x and write G (4 pixels per row when pooled).  The kernel also READS G (it accumulates into it): that
+    // read is traffic, not algorithm -- with it the count would be K + 3 px N.
     const double px = a.epi == EPI_DGRAD_POOL ? 4.0 : 1.0;
-    const double bytes = (double)a.M * 2.0 * (a.K + (a.epi == EPI_FWD ? (double)a.N : 3.0 * px * a.N));
+    const double bytes = (double)a.M * 2.0 * (a.K + (a.epi == EPI_FWD ? (double)a.N : 2.0 * px * a.N));
     ProfScope ps(label, 2.0 * a.M * (double)a.N * a.K, bytes, st);
     const dim3 grid(gemm_nt_nblk(a), cdiv(a.N, 128));
     const bool xf = a.epi == EPI_FWD && a.asc != nullptr;

@@ -392,7 +392,7 @@ bool pool0_bwd_vec_ok(const Pool0BwdArgs& a) {
 int pool0_bwd_vec(const Pool0BwdArgs& a, hipStream_t st) {
     if (!pool0_bwd_vec_ok(a)) return -2;
     if (a.nblk != pool0_bwd_vec_grid(a.n_img, a.Hin, a.Win)) return -3;
-    static const bool old = getenv("TCVN_POOL0_BWD_FLAT") != nullptr;        // A/B switch
+    static const bool old = TCVN_KNOB_SET("TCVN_POOL0_BWD_FLAT");        // A/B switch
     if (a.C == 64 && !old) {
         hipLaunchKernelGGL(k_pool0_bwd_tile, dim3(a.nblk), dim3(256), 0, st, a, cdiv(a.Win, PB_TW), cdiv(a.Hin, PB_TH));
         TCVN_LAUNCH_CHECK();

@@ -3,6 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+
+// Validation / ablation switches exist only in builds made with -DTCVN_DEBUG_KNOBS (`make debug` -> libtcvn_hip_dbg.so, used by
+// the tests that compare kernel variants).  The default library reads no environment variable and contains none of the
+// work-dropping branches: TCVN_KNOB_* fold to constants and the compiler removes the code behind them.
+#ifdef TCVN_DEBUG_KNOBS
+#define TCVN_KNOB_INT(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#define TCVN_KNOB_SET(name) (getenv(name) != nullptr)
+#define TCVN_DBG_BIT(v, bit) (((v) & (bit)) != 0)
+#else
+#define TCVN_KNOB_INT(name) 0
+#define TCVN_KNOB_SET(name) false
+#define TCVN_DBG_BIT(v, bit) false
+#endif
 
 namespace tcvn {
 

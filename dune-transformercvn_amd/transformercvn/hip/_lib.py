@@ -12,7 +12,9 @@ import torch  # noqa: F401  -- first: the library must bind to the HIP runtime P
 #                              /opt/rocm's copy ahead of torch's leaves this library without a device ("no ROCm-capable device")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libtcvn_hip.so"))
+# TCVN_HIP_LIBRARY names another build in the same directory -- only the variant tests use it, to load libtcvn_hip_dbg.so
+# (the -DTCVN_DEBUG_KNOBS build that honours the validation switches) in a child process.
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", os.path.basename(os.environ.get("TCVN_HIP_LIBRARY", "libtcvn_hip.so"))))
 
 MODE_F32, MODE_BF16 = 0, 1
 SLOT_PARAM, SLOT_BUFFER, SLOT_COUNTER = 0, 1, 2
@@ -68,6 +70,7 @@ def _load():
     sig("tcvn_focal_loss", i32, vp, vp, i32, i32, f32, f32, vp, vp, vp)
     sig("tcvn_grad_sumsq", i32, vp, i64, vp, i32, vp, vp)
     sig("tcvn_adamw_step", i32, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, f32, vp)
+    sig("tcvn_dropout_keep", i32, i32, f32, u64, C.c_uint32, i64, i32, vp, vp)
     sig("tcvn_backward_overlap", None, i32)
     sig("tcvn_profile_enable", None, i32)
     sig("tcvn_profile_filter", None, C.c_char_p)
@@ -90,7 +93,7 @@ def profile_records():
 
 EXPORTS = [
     "tcvn_grad_sumsq", "tcvn_adamw_step", "tcvn_backward_overlap", "tcvn_profile_enable", "tcvn_profile_filter", "tcvn_profile_reset", "tcvn_profile_count", "tcvn_profile_get",
-    "tcvn_focal_loss",
+    "tcvn_focal_loss", "tcvn_dropout_keep",
     "tcvn_version", "tcvn_densenet_create", "tcvn_densenet_destroy", "tcvn_densenet_num_slots", "tcvn_densenet_slot",
     "tcvn_densenet_bind", "tcvn_densenet_workspace_bytes", "tcvn_densenet_forward", "tcvn_densenet_backward",
     "tcvn_densenet_tap", "tcvn_head_create", "tcvn_head_destroy", "tcvn_head_num_slots", "tcvn_head_slot", "tcvn_head_bind",

@@ -210,6 +210,8 @@ class HipRuntime:
         in_dim = feat + pix + pos
         seed = (self.seed * 1000003 + self.step) & 0x7FFFFFFFFFFFFFFF
         self.step += 1
+        # seeds of the three native plans for this step (validation: tcvn_dropout_keep replays the masks from them)
+        self.last_seeds = {"event": seed ^ 0x1111, "prong": seed ^ 0x2222, "head": seed ^ 0x3333}
         with torch.no_grad():
             rows = torch.zeros(B + n_prongs, in_dim, device=dev)
             rows[:, feat + pix:] = self._pos            # prongs also get the *event* position embedding (reference quirk)

@@ -73,7 +73,7 @@ int tcvn_densenet_forward(tcvn_densenet* p, int n_img, const int32_t* coords, co
 int tcvn_densenet_backward(tcvn_densenet* p, int n_img, const float* d_out, int64_t d_out_ld, void* workspace,
                            int64_t workspace_bytes, void* stream);
 
-/* Debug/validation taps into the workspace of the last forward: name in {"conv0","dense<b>","bottleneck<b>.<l>","condense"},
+/* Debug/validation taps into the workspace of the last forward: name in {"img","conv0","dense<b>","bottleneck<b>.<l>","condense"},
  * in bf16 mode also the materialised operands "xa<b>.<l>" / "ya<b>.<l>" and the raw regions "raw:wk","raw:tabs","raw:bstat<b>";
  * returns the byte offset into the workspace and the logical NHWC shape + channel stride + element size. */
 int tcvn_densenet_tap(const tcvn_densenet* p, int n_img, const char* name, int64_t* byte_off, int* n, int* h, int* w,
@@ -139,6 +139,17 @@ int tcvn_grad_sumsq(const float* x, int64_t n, double* partials, int n_partials,
  * to the gradient on the fly (the gradient arena itself is left as is).  step is 1-based. */
 int tcvn_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* weight_decay, int64_t n,
                     float lr, float beta1, float beta2, float eps, int64_t step, const float* grad_sumsq, float clip, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Validation aid: the dropout keep-scale (0 or 1/(1-p)) the kernels apply at one site, as a [rows, cols] fp32 tensor.
+ * Masks are never stored: forward and backward recompute them from (seed, stream id, element).  kind 0: sites indexed by the
+ * row-major element number (output block 0x4000, combined embedding 0x5000, encoder layer l 0x6000+8l+{0 attention
+ * probabilities [B,H,S,S], 1 attention output, 2 FFN activation, 3 FFN output} [T,D], prong decoder 0x7000+i); kind 1: the
+ * 3x3 convolution outputs of dense block b, layer l (stream id 64 b + l + 1; rows = pixels n*H*W, cols = growth).
+ * The reference draws its masks from torch's global generator (layers/dense_net.py:29-40 via nn.Dropout); only the
+ * distribution is comparable, so tests feed these masks to the CPU oracle.
+ * --------------------------------------------------------------------------------------------------------------- */
+int tcvn_dropout_keep(int kind, float p, uint64_t seed, uint32_t stream_id, int64_t rows, int cols, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline leg): when enabled, every convolution launch is bracketed by a HIP event pair on

@@ -355,9 +355,14 @@ def preprocess_pixels(cfg, coords: Tensor, values: Tensor, training: bool, noise
 class _Ctx:
     """Carries mode flags, collects intermediates and BN running-stat updates."""
 
-    def __init__(self, training: bool, dropout: float = 0.0):
+    def __init__(self, training: bool, dropout: float = 0.0, mask_provider=None):
         self.training = training
         self.dropout = dropout
+        # mask_provider(site: str, shape) -> keep-scale tensor (0 or 1/(1-p)) replaces torch's generator at every dropout
+        # site, so that a GPU step's counter-based masks can be replayed here (tests/test_dropout_noise_gpu.py).  Sites:
+        # "<densenet prefix>:dense<b>.<l>" [n,g,H,W], "<densenet prefix>:out" [n,out], "<linear block prefix>" [rows,D],
+        # "<encoder layer prefix>:attn" [B*H,S,S], ":sa" / ":ffn_act" / ":ffn" [S,B,D], "decoder.<i>" [T*B,width].
+        self.mask_provider = mask_provider
         self.taps: Dict[str, Tensor] = {}
         self.new_running: Dict[str, Tensor] = {}
 
@@ -387,8 +392,12 @@ def _prelu(x: Tensor, slope: Tensor) -> Tensor:
     return torch.where(x > 0, x, s * x)
 
 
-def _dropout(x: Tensor, ctx: _Ctx) -> Tensor:
-    return F.dropout(x, ctx.dropout, True) if (ctx.training and ctx.dropout > 0) else x
+def _dropout(x: Tensor, ctx: _Ctx, site: str = "") -> Tensor:
+    if not (ctx.training and ctx.dropout > 0):
+        return x
+    if ctx.mask_provider is not None:
+        return x * ctx.mask_provider(site, tuple(x.shape)).to(x.dtype)
+    return F.dropout(x, ctx.dropout, True)
 
 
 def densenet_forward(sd, prefix: str, cfg, x: Tensor, ctx: _Ctx) -> Tensor:
@@ -409,7 +418,7 @@ def densenet_forward(sd, prefix: str, cfg, x: Tensor, ctx: _Ctx) -> Tensor:
                 ctx.taps[f"{prefix}:dense{b + 1}.bottleneck0"] = y
             y = _prelu(_batch_norm(sd, p + ".output_block.norm2", y, ctx), sd[p + ".output_block.relu2.weight"])
             y = F.conv2d(y, sd[p + ".output_block.conv2.weight"], sd[p + ".output_block.conv2.bias"], padding=1)
-            y = _dropout(y, ctx)
+            y = _dropout(y, ctx, f"{prefix}:dense{b + 1}.{i}")
             x = torch.cat((x, y), dim=1)
         ctx.taps[f"{prefix}:dense{b + 1}"] = x
         if b != nblocks - 1:
@@ -424,7 +433,7 @@ def densenet_forward(sd, prefix: str, cfg, x: Tensor, ctx: _Ctx) -> Tensor:
     o = prefix + ".output_block"
     x = F.linear(x, sd[o + ".linear.weight"])
     x = _prelu(_batch_norm(sd, o + ".norm", x, ctx), sd[o + ".relu.weight"])
-    x = _dropout(x, ctx)
+    x = _dropout(x, ctx, prefix + ":out")
     ctx.taps[prefix + ":out"] = x
     return x
 
@@ -435,7 +444,7 @@ def linear_block(sd, prefix: str, cfg, x: Tensor, ctx: _Ctx) -> Tensor:
     if cfg.linear_batch_norm:
         x = _batch_norm(sd, prefix + ".norm", x, ctx)
     x = _prelu(x, sd[prefix + ".activation.weight"]) if cfg.linear_prelu_activation else F.relu(x)
-    return _dropout(x, ctx)
+    return _dropout(x, ctx, prefix)
 
 
 def pack_indices(mask: Tensor) -> Tuple[Tensor, Tensor]:
@@ -492,14 +501,14 @@ def encoder_layer_forward(sd, p: str, cfg, x: Tensor, key_padding: Tensor, ctx: 
         scores = torch.bmm(q * (1.0 / math.sqrt(hd)), k.transpose(1, 2))      # [B*H,S,S]
         bias = torch.zeros(B, 1, 1, S, dtype=x.dtype).masked_fill(key_padding.view(B, 1, 1, S), float("-inf"))
         scores = (scores.view(B, H, S, S) + bias).view(B * H, S, S)
-        attn = _dropout(torch.softmax(scores, dim=-1), ctx)
+        attn = _dropout(torch.softmax(scores, dim=-1), ctx, p + ":attn")
         o = torch.bmm(attn, vv).transpose(0, 1).reshape(S, B, D)
         o = F.linear(o, sd[p + ".self_attn.out_proj.weight"], sd[p + ".self_attn.out_proj.bias"])
-        return _dropout(o, ctx)
+        return _dropout(o, ctx, p + ":sa")
 
     def ff(v):
-        h = _dropout(act(F.linear(v, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])), ctx)
-        return _dropout(F.linear(h, sd[p + ".linear2.weight"], sd[p + ".linear2.bias"]), ctx)
+        h = _dropout(act(F.linear(v, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])), ctx, p + ":ffn_act")
+        return _dropout(F.linear(h, sd[p + ".linear2.weight"], sd[p + ".linear2.bias"]), ctx, p + ":ffn")
 
     def ln(v, n):
         return F.layer_norm(v, (D,), sd[f"{p}.{n}.weight"], sd[f"{p}.{n}.bias"], LN_EPS)
@@ -534,7 +543,7 @@ def decoders_forward(sd, cfg, hidden: Tensor, ctx: _Ctx) -> Tuple[Tensor, Tensor
     dims, _ = prong_decoder_dims(cfg)
     idx = 0
     p = "network.prong_decoder.hidden_layers"
-    for _ in dims:
+    for di, _ in enumerate(dims):
         h = F.linear(h, sd[f"{p}.{idx}.weight"], sd[f"{p}.{idx}.bias"])
         idx += 1
         if cfg.linear_batch_norm:
@@ -543,19 +552,19 @@ def decoders_forward(sd, cfg, hidden: Tensor, ctx: _Ctx) -> Tuple[Tensor, Tensor
         h = _prelu(h, sd[f"{p}.{idx}.weight"]) if cfg.linear_prelu_activation else F.relu(h)
         idx += 1
         if cfg.dropout > 0.0:
-            h = _dropout(h, ctx)
+            h = _dropout(h, ctx, f"decoder.{di}")
             idx += 1
     h = F.linear(h, sd["network.prong_decoder.output_layer.weight"], sd["network.prong_decoder.output_layer.bias"])
     return ev, h.reshape(T, B, -1).transpose(0, 1)
 
 
 def forward(sd, cfg, batch8: Tuple[Tensor, ...], training: bool = False, apply_dropout: bool = False,
-            noise: Optional[Tuple[Tensor, Tensor]] = None):
+            noise: Optional[Tuple[Tensor, Tensor]] = None, mask_provider=None):
     """trainers/neutrino_full_base_trainer.py:90-116 followed by networks/neutrino_full_base_network.py:166-188.
     Returns (event_logits [B,Ce], prong_logits [B,P,Cp], ctx)."""
     features, extra, event_coords, event_values, event_mask, prong_coords, prong_values, prong_mask = batch8
     dt = sd["network.event_decoder.hidden_layer.weight"].dtype
-    ctx = _Ctx(training, cfg.dropout if apply_dropout else 0.0)
+    ctx = _Ctx(training, cfg.dropout if apply_dropout else 0.0, mask_provider)
     features = features.clone().to(dt)
     extra = extra.clone().to(dt)
     if cfg.normalize_features:
@@ -569,12 +578,12 @@ def forward(sd, cfg, batch8: Tuple[Tensor, ...], training: bool = False, apply_d
     return ev, pr, ctx
 
 
-def shared_step(sd, cfg, batch10, training: bool, apply_dropout: bool = False):
+def shared_step(sd, cfg, batch10, training: bool, apply_dropout: bool = False, noise=None, mask_provider=None):
     """trainers/neutrino_full_base_trainer.py:118-146 (truncate to the max real prong count)."""
     features, extra, ec, evv, em, pc, pv, pm, et, pt = batch10
     mp = int(pm.sum(1).max())
     ev, pr, ctx = forward(sd, cfg, (features[:, :mp].contiguous(), extra, ec, evv, em, pc, pv, pm[:, :mp].contiguous()),
-                          training, apply_dropout)
+                          training, apply_dropout, noise, mask_provider)
     return et, pt[:, :mp].contiguous(), ev, pr, ctx
 
 
@@ -596,7 +605,7 @@ def training_loss(cfg, event_logits, prong_logits, event_targets, prong_targets)
     return s * el + (1.0 - s) * pl, el, pl
 
 
-def train_step(sd, cfg, batch10, apply_dropout: bool = False):
+def train_step(sd, cfg, batch10, apply_dropout: bool = False, noise=None, mask_provider=None):
     """One forward+backward of training_step; returns (losses, logits, grads dict, ctx).
     Gradients are taken w.r.t. every floating-point entry of `sd` that is not a BN running statistic
     or a normalisation constant."""
@@ -609,7 +618,7 @@ def train_step(sd, cfg, batch10, apply_dropout: bool = False):
             sd2[k] = leaves[k]
         else:
             sd2[k] = v
-    et, pt, ev, pr, ctx = shared_step(sd2, cfg, batch10, True, apply_dropout)
+    et, pt, ev, pr, ctx = shared_step(sd2, cfg, batch10, True, apply_dropout, noise, mask_provider)
     total, el, pl = training_loss(cfg, ev, pr, et, pt)
     names = list(leaves)
     gs = torch.autograd.grad(total, [leaves[n] for n in names], allow_unused=True)

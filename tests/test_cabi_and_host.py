@@ -27,6 +27,19 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) <= declared
 
 
+def test_product_library_has_no_environment_switches():
+    """The shipped library must not change behaviour with the environment: the validation / ablation knobs (TCVN_DBG,
+    TCVN_DISABLE_TILE, ...) exist only in the -DTCVN_DEBUG_KNOBS build (libtcvn_hip_dbg.so)."""
+    import subprocess
+    from transformercvn.hip import _lib
+    assert os.path.basename(_lib.LIB_PATH) == "libtcvn_hip.so"
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for knob in (b"TCVN_DBG", b"TCVN_DISABLE_TILE", b"TCVN_XA_ONTHEFLY", b"TCVN_BWD_SERIAL", b"TCVN_POOL0_BWD_FLAT"):
+        assert knob not in blob, knob
+
+
 def test_densenet_plan_slots_match_reference_layout():
     from transformercvn.hip.engine import DenseNetEngine
     cfg = O.tutorial_config()

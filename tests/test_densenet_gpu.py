@@ -171,7 +171,7 @@ def test_densenet_bf16_close_to_fp32_oracle(name, training):
 
 @pytest.mark.parametrize("name", ["mid"])
 def test_bf16_tile_kernels_match_generic_kernels(name, monkeypatch):
-    """The padded-tile 3x3 kernels against the generic implicit-GEMM kernels (TCVN_DISABLE_TILE=1, separate process) on
+    """The padded-tile 3x3 kernels against the generic implicit-GEMM kernels (TCVN_DISABLE_TILE=1 on the -DTCVN_DEBUG_KNOBS build, separate process) on
     identical bf16 inputs: same products, different summation order only."""
     import subprocess, sys, os, json
     cfg, over, batch, g = _mid_case() if name == "mid" else load_case(name)
@@ -194,7 +194,7 @@ d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().man
 out, taps, grads = T._run_bf16(cfg, sd, batch, True, d_out)
 torch.save(dict(out=out, taps=taps, grads=grads), {('/tmp/tcvn_generic_' + name + '.pt')!r})
 """
-    env = dict(os.environ, TCVN_DISABLE_TILE="1")
+    env = dict(os.environ, TCVN_DISABLE_TILE="1", TCVN_HIP_LIBRARY="libtcvn_hip_dbg.so")
     subprocess.check_call([sys.executable, "-c", code], env=env)
     ref = torch.load("/tmp/tcvn_generic_" + name + ".pt")
     e_out = ((out - ref["out"]).norm() / ref["out"].norm()).item()
@@ -249,7 +249,7 @@ d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().man
 out, taps, grads = T._run_bf16(cfg, sd, batch, True, d_out)
 torch.save(dict(out=out, taps=taps, grads=grads), '/tmp/tcvn_fallback_mid.pt')
 """
-    env = dict(os.environ, TCVN_DBG="32", TCVN_POOL0_BWD_FLAT="1")
+    env = dict(os.environ, TCVN_DBG="32", TCVN_POOL0_BWD_FLAT="1", TCVN_HIP_LIBRARY="libtcvn_hip_dbg.so")
     subprocess.check_call([sys.executable, "-c", code], env=env)
     ref = torch.load("/tmp/tcvn_fallback_mid.pt")
     e_out = ((out - ref["out"]).norm() / ref["out"].norm()).item()
