@@ -35,11 +35,34 @@ def note(msg):
 
 
 def host_threads():
-    """CPU threads this process may actually use: every core of the affinity mask (all physical cores)."""
+    """CPU threads this process may actually use (all cores it has): the affinity mask, limited by the cgroup
+    CPU quota when there is one (a GPU box hands each lease a share of the host, e.g. 16 of 256 cores: running 256 threads on
+    a 16-core quota is several times slower than 16 threads).  Without a readable quota the share the harness documents (16)
+    caps it."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    quota = int(parts[0]) / int(parts[1])
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        quota = q / int(f2.read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    else:
+        n = min(n, 16)
     return max(1, n)
 
 
@@ -74,19 +97,21 @@ def cpu_baseline(threads, prongs):
     sd = O.fill_state(cfg, 1)
     ev = 4
     batch = O.synthetic_batch([prongs] * ev, 11, cfg)
+    t0 = time.perf_counter()
     O.train_step(sd, cfg, batch, apply_dropout=True)               # warm-up (oneDNN primitive creation)
+    warm = time.perf_counter() - t0
     ts = []
-    for _ in range(3):
+    for _ in range(3 if warm < 12 else 1):                         # bounded: about 10-30 s of CPU work in all
         t0 = time.perf_counter()
         O.train_step(sd, cfg, batch, apply_dropout=True)
         ts.append(time.perf_counter() - t0)
     ts.sort()
-    note(f"cpu baseline: {cpu_model()}, os.cpu_count()={os.cpu_count()}, affinity {threads}, torch threads {torch.get_num_threads()}, "
-         f"steps {[round(t, 2) for t in ts]} s")
-    return {"value": round(ev / ts[1], 3), "unit": "events/s", "cores": threads, "kind": "port",
+    note(f"cpu baseline: {cpu_model()}, os.cpu_count()={os.cpu_count()}, threads used {threads}, torch threads "
+         f"{torch.get_num_threads()}, warm-up {warm:.2f} s, steps {[round(t, 2) for t in ts]} s")
+    return {"value": round(ev / ts[len(ts) // 2], 3), "unit": "events/s", "cores": threads, "kind": "port",
             "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(),
             "sample": f"oracle fp32 fwd+loss+bwd, {ev} events x {prongs} prongs ({ev * (1 + prongs)} maps), 6-layer encoder, dropout 0.1, "
-                      "median of 3 steps after 1 warm-up"}
+                      f"median of {len(ts)} steps after 1 warm-up"}
 
 
 def fp32_parity_mode_ms(opt_path, args, dev, batch):

@@ -132,28 +132,29 @@ void HeadPlan::layout(int B, int P, int nP, HLayout& L) const {
     L.total = b.off;
 }
 
-int HeadPlan::forward(int B, int P, int nP, const float* rows, const int32_t* tok_row, float* ev_logits, float* pr_logits,
-                      char* ws, long ws_bytes, int train, uint64_t seed, hipStream_t st) {
-    if (!bound) return -11;
-    if (cfg.norm_first) { fprintf(stderr, "tcvn: transformer_norm_first is not implemented\n"); return -20; }
-    if (cfg.dec_out_in != dec_width) { fprintf(stderr, "tcvn: prong decoder width mismatch (reference would fail too)\n"); return -21; }
-    HLayout L;
-    layout(B, P, nP, L);
-    if (ws_bytes < L.total) return -12;
-    const int D = cfg.hidden_dim, S = 1 + P, T = S * B, R = B + nP, TP = P * B, H = cfg.heads, hd = D / H;
+// ---- stage 1: combined embedding (LinearBlock over event + packed prong rows) and the token gather -> L.X[0] ------------
+int HeadPlan::embed(int B, int P, int nP, const float* rows, const int32_t* tok_row, char* ws, const HLayout& L, int train,
+                    uint64_t seed, hipStream_t st) {
+    const int D = cfg.hidden_dim, S = 1 + P, R = B + nP;
     const float dp = train ? cfg.dropout : 0.f;
     auto F = [&](long off) { return reinterpret_cast<float*>(ws + off); };
     int rc;
     if ((rc = linear_fwd(rows, cfg.in_dim, data[cw], nullptr, F(L.Zc), D, R, D, cfg.in_dim, st))) return rc;
-    {
-        RowsBnArgs r{};
-        r.X = F(L.Zc); r.ldx = D; r.R = R; r.C = D; r.gamma = data[cn.w]; r.beta = data[cn.b]; r.slope = data[ca];
-        r.running_mean = data[cn.rm]; r.running_var = data[cn.rv]; r.Y = F(L.C); r.ldy = D;
-        r.save_mean = F(L.cstat); r.save_rstd = F(L.cstat) + D; r.train = train; r.eps = kEps; r.momentum = kMom;
-        r.drop_p = dp; r.seed = seed; r.stream_id = 0x5000u;
-        if ((rc = rows_bn_fwd(r, st))) return rc;
-    }
-    if ((rc = gather_tokens(F(L.C), tok_row, F(L.X[0]), B, S, D, st))) return rc;
+    RowsBnArgs r{};
+    r.X = F(L.Zc); r.ldx = D; r.R = R; r.C = D; r.gamma = data[cn.w]; r.beta = data[cn.b]; r.slope = data[ca];
+    r.running_mean = data[cn.rm]; r.running_var = data[cn.rv]; r.Y = F(L.C); r.ldy = D;
+    r.save_mean = F(L.cstat); r.save_rstd = F(L.cstat) + D; r.train = train; r.eps = kEps; r.momentum = kMom;
+    r.drop_p = dp; r.seed = seed; r.stream_id = 0x5000u;
+    if ((rc = rows_bn_fwd(r, st))) return rc;
+    return gather_tokens(F(L.C), tok_row, F(L.X[0]), B, S, D, st);
+}
+
+// ---- stage 2: transformer encoder, L.X[0] (sequence-major tokens, padding rows zero) -> L.HID (masked) ------------------
+int HeadPlan::encode(int B, int P, const int32_t* tok_row, char* ws, const HLayout& L, int train, uint64_t seed, hipStream_t st) {
+    const int D = cfg.hidden_dim, S = 1 + P, T = S * B, H = cfg.heads, hd = D / H;
+    const float dp = train ? cfg.dropout : 0.f;
+    auto F = [&](long off) { return reinterpret_cast<float*>(ws + off); };
+    int rc;
     for (int l = 0; l < cfg.n_layers; ++l) {
         const HLayer& W = layers[l];
         const HLayBuf& q = L.lay[l];
@@ -170,8 +171,18 @@ int HeadPlan::forward(int B, int P, int nP, const float* rows, const int32_t* to
         AddLnArgs n2{F(q.x1), F(q.f), data[W.g2], data[W.be2], F(L.X[l + 1]), F(q.xh2), F(q.rstd2), T, D, kEps, dp, seed, sid + 3};
         if ((rc = add_ln_fwd(n2, st))) return rc;
     }
-    if ((rc = mask_rows(F(L.X[cfg.n_layers]), tok_row, F(L.HID), B, S, D, st))) return rc;
-    if ((rc = linear_fwd(F(L.HID), D, data[ew], data[eb], ev_logits, cfg.event_classes, B, cfg.event_classes, D, st))) return rc;
+    return mask_rows(F(L.X[cfg.n_layers]), tok_row, F(L.HID), B, S, D, st);
+}
+
+// ---- stage 3: event decoder on token 0, prong decoder on tokens 1..P of L.HID -------------------------------------------
+int HeadPlan::decode(int B, int P, float* ev_logits, float* pr_logits, char* ws, const HLayout& L, int train, uint64_t seed,
+                     hipStream_t st) {
+    const int D = cfg.hidden_dim, TP = P * B;
+    const float dp = train ? cfg.dropout : 0.f;
+    auto F = [&](long off) { return reinterpret_cast<float*>(ws + off); };
+    int rc;
+    if (ev_logits && (rc = linear_fwd(F(L.HID), D, data[ew], data[eb], ev_logits, cfg.event_classes, B, cfg.event_classes, D, st))) return rc;
+    if (!pr_logits || TP == 0) return 0;
     const float* in = F(L.HID) + (long)B * D;
     int inw = D;
     for (size_t i = 0; i < dec.size(); ++i) {
@@ -186,7 +197,26 @@ int HeadPlan::forward(int B, int P, int nP, const float* rows, const int32_t* to
         in = F(L.Ad[i]); inw = d.out;
     }
     if ((rc = linear_fwd(in, inw, data[ow], data[ob], F(L.LG), cfg.prong_classes, TP, cfg.prong_classes, cfg.dec_out_in, st))) return rc;
-    if ((rc = permute_rows(F(L.LG), pr_logits, B, P, cfg.prong_classes, 1, st))) return rc;
+    return permute_rows(F(L.LG), pr_logits, B, P, cfg.prong_classes, 1, st);
+}
+
+int HeadPlan::check(int B, int P, int nP, long ws_bytes, HLayout& L) const {
+    if (!bound) return -11;
+    if (cfg.norm_first) { fprintf(stderr, "tcvn: transformer_norm_first is not implemented\n"); return -20; }
+    if (cfg.dec_out_in != dec_width) { fprintf(stderr, "tcvn: prong decoder width mismatch (reference would fail too)\n"); return -21; }
+    if (B <= 0 || P < 0 || nP < 0 || 1 + P > 64) return -1;          // attention kernel: sequences up to 64 tokens
+    layout(B, P, nP, L);
+    return ws_bytes < L.total ? -12 : 0;
+}
+
+int HeadPlan::forward(int B, int P, int nP, const float* rows, const int32_t* tok_row, float* ev_logits, float* pr_logits,
+                      char* ws, long ws_bytes, int train, uint64_t seed, hipStream_t st) {
+    HLayout L;
+    int rc;
+    if ((rc = check(B, P, nP, ws_bytes, L))) return rc;
+    if ((rc = embed(B, P, nP, rows, tok_row, ws, L, train, seed, st))) return rc;
+    if ((rc = encode(B, P, tok_row, ws, L, train, seed, st))) return rc;
+    if ((rc = decode(B, P, ev_logits, pr_logits, ws, L, train, seed, st))) return rc;
     last_seed = seed; last_train = train;
     return 0;
 }
@@ -314,6 +344,44 @@ int tcvn_head_forward(tcvn_head* p, int batch, int max_prongs, int n_prongs, con
     return p->plan.forward(batch, max_prongs, n_prongs, rows, tok_row, event_logits, prong_logits, reinterpret_cast<char*>(ws),
                            ws_bytes, train, seed, reinterpret_cast<hipStream_t>(stream));
 }
+/* stage entry points (forward only): see include/tcvn_hip.h */
+int tcvn_head_embed(tcvn_head* p, int batch, int max_prongs, int n_prongs, const float* rows, const int32_t* tok_row, float* tokens,
+                    void* ws, int64_t ws_bytes, int train, uint64_t seed, void* stream) {
+    HLayout L;
+    int rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if ((rc = p->plan.check(batch, max_prongs, n_prongs, ws_bytes, L))) return rc;
+    char* w = reinterpret_cast<char*>(ws);
+    if ((rc = p->plan.embed(batch, max_prongs, n_prongs, rows, tok_row, w, L, train, seed, st))) return rc;
+    return permute_rows(reinterpret_cast<float*>(w + L.X[0]), tokens, batch, 1 + max_prongs, p->plan.cfg.hidden_dim, 1, st);
+}
+int tcvn_head_encode(tcvn_head* p, int batch, int max_prongs, const float* tokens, const int32_t* tok_row, float* hidden, void* ws,
+                     int64_t ws_bytes, int train, uint64_t seed, void* stream) {
+    HLayout L;
+    int rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if ((rc = p->plan.check(batch, max_prongs, 0, ws_bytes, L))) return rc;
+    char* w = reinterpret_cast<char*>(ws);
+    const int D = p->plan.cfg.hidden_dim, S = 1 + max_prongs;
+    float* X0 = reinterpret_cast<float*>(w + L.X[0]);
+    if ((rc = permute_rows(tokens, X0, batch, S, D, 0, st))) return rc;            // [B,S,D] -> sequence-major rows
+    if ((rc = mask_rows(X0, tok_row, X0, batch, S, D, st))) return rc;             // embeddings * sequence_mask (:69)
+    if ((rc = p->plan.encode(batch, max_prongs, tok_row, w, L, train, seed, st))) return rc;
+    TCVN_CHECK(hipMemcpyAsync(hidden, w + L.HID, (size_t)S * batch * D * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+int tcvn_head_decode(tcvn_head* p, int batch, int max_prongs, const float* hidden, float* event_logits, float* prong_logits,
+                     void* ws, int64_t ws_bytes, int train, uint64_t seed, void* stream) {
+    HLayout L;
+    int rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if ((rc = p->plan.check(batch, max_prongs, 0, ws_bytes, L))) return rc;
+    char* w = reinterpret_cast<char*>(ws);
+    const int D = p->plan.cfg.hidden_dim, S = 1 + max_prongs;
+    TCVN_CHECK(hipMemcpyAsync(w + L.HID, hidden, (size_t)S * batch * D * 4, hipMemcpyDeviceToDevice, st));
+    return p->plan.decode(batch, max_prongs, event_logits, prong_logits, w, L, train, seed, st);
+}
+
 int tcvn_head_loss(tcvn_head* p, int batch, int max_prongs, const float* event_logits, const float* prong_logits,
                    const int64_t* event_targets, const int8_t* prong_targets, float* losses, float* accs, float* d_event_logits,
                    float* d_prong_logits, void* stream) {
@@ -326,6 +394,27 @@ int tcvn_head_backward(tcvn_head* p, int batch, int max_prongs, int n_prongs, co
     return p->plan.backward(batch, max_prongs, n_prongs, rows, tok_row, d_event_logits, d_prong_logits, d_rows,
                             reinterpret_cast<char*>(ws), ws_bytes, reinterpret_cast<hipStream_t>(stream));
 }
+}
+
+// Stand-alone row operators behind the holder modules' own forward() (LinearBlock, ProngDecoder, ProngTargetDecoder,
+// DenseNet.output_block): forward only, fp32, caller-owned tensors.
+extern "C" int tcvn_linear_forward(const float* x, int64_t ldx, const float* weight, const float* bias, float* y, int64_t ldy,
+                                   int rows, int n_out, int n_in, void* stream) {
+    if (!x || !weight || !y || rows < 0 || n_out <= 0 || n_in <= 0) return -1;
+    if (rows == 0) return 0;
+    return linear_fwd(x, ldx, weight, bias, y, ldy, rows, n_out, n_in, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int tcvn_rows_bn_prelu_forward(const float* x, int64_t ldx, int rows, int channels, const float* gamma, const float* beta,
+                                          const float* slope, float* running_mean, float* running_var, float* y, int64_t ldy,
+                                          float* save_mean_rstd, int train, float drop_p, uint64_t seed, uint32_t stream_id,
+                                          void* stream) {
+    if (!x || !y || !gamma || !beta || !slope || !running_mean || !running_var || !save_mean_rstd || rows <= 0 || channels <= 0) return -1;
+    RowsBnArgs r{};
+    r.X = x; r.ldx = ldx; r.R = rows; r.C = channels; r.gamma = gamma; r.beta = beta; r.slope = slope;
+    r.running_mean = running_mean; r.running_var = running_var; r.Y = y; r.ldy = ldy;
+    r.save_mean = save_mean_rstd; r.save_rstd = save_mean_rstd + channels; r.train = train; r.eps = kEps; r.momentum = kMom;
+    r.drop_p = train ? drop_p : 0.f; r.seed = seed; r.stream_id = stream_id;
+    return rows_bn_fwd(r, reinterpret_cast<hipStream_t>(stream));
 }
 
 // Stand-alone softmax focal loss of one logit matrix (reference: NeutrinoFullBaseTrainer.loss, :148-160)

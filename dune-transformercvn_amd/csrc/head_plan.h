@@ -35,6 +35,11 @@ struct HeadPlan {
     HBn add_bn(const std::string& p, int c);
     int bind(void* const* d, void* const* g);
     void layout(int B, int P, int nP, HLayout& L) const;
+    int check(int B, int P, int nP, long ws_bytes, HLayout& L) const;
+    int embed(int B, int P, int nP, const float* rows, const int32_t* tok_row, char* ws, const HLayout& L, int train, uint64_t seed,
+              hipStream_t st);
+    int encode(int B, int P, const int32_t* tok_row, char* ws, const HLayout& L, int train, uint64_t seed, hipStream_t st);
+    int decode(int B, int P, float* ev_logits, float* pr_logits, char* ws, const HLayout& L, int train, uint64_t seed, hipStream_t st);
     int forward(int B, int P, int nP, const float* rows, const int32_t* tok_row, float* ev_logits, float* pr_logits, char* ws,
                 long ws_bytes, int train, uint64_t seed, hipStream_t st);
     int loss(int B, int P, const float* ev_logits, const float* pr_logits, const int64_t* et, const int8_t* pt, float* losses,

@@ -159,6 +159,42 @@ class HeadEngine(_Plan):
                                     _ptr(ws), ws.numel(), int(train), C.c_uint64(seed), _stream_ptr()), "head_forward")
         return ev, pr
 
+    def _stage_ws(self, batch: int, max_prongs: int, n_prongs: int, device):
+        return self.workspace(lib.tcvn_head_workspace_bytes(self.handle, batch, max_prongs, n_prongs), device)
+
+    def embed(self, rows: torch.Tensor, tok_row: torch.Tensor, batch: int, max_prongs: int, n_prongs: int, train: bool,
+              seed: int = 0) -> torch.Tensor:
+        """tcvn_head_embed: -> tokens [batch, 1+max_prongs, hidden] (forward only)."""
+        assert rows.dtype == torch.float32 and rows.is_contiguous() and rows.shape == (batch + n_prongs, self.cfg.in_dim)
+        assert tok_row.dtype == torch.int32 and tok_row.is_contiguous() and tok_row.shape == (batch, 1 + max_prongs)
+        ws = self._stage_ws(batch, max_prongs, n_prongs, rows.device)
+        tokens = torch.empty(batch, 1 + max_prongs, self.cfg.hidden_dim, device=rows.device)
+        check(lib.tcvn_head_embed(self.handle, batch, max_prongs, n_prongs, _ptr(rows), _ptr(tok_row), _ptr(tokens), _ptr(ws),
+                                  ws.numel(), int(train), C.c_uint64(seed), _stream_ptr()), "head_embed")
+        return tokens
+
+    def encode(self, tokens: torch.Tensor, tok_row: torch.Tensor, train: bool, seed: int = 0) -> torch.Tensor:
+        """tcvn_head_encode: tokens [B, S, hidden] -> hidden [S, B, hidden] (forward only)."""
+        batch, S, D = tokens.shape
+        assert D == self.cfg.hidden_dim and tokens.dtype == torch.float32 and tokens.is_contiguous()
+        assert tok_row.dtype == torch.int32 and tok_row.is_contiguous() and tok_row.shape == (batch, S)
+        ws = self._stage_ws(batch, S - 1, 0, tokens.device)
+        hidden = torch.empty(S, batch, D, device=tokens.device)
+        check(lib.tcvn_head_encode(self.handle, batch, S - 1, _ptr(tokens), _ptr(tok_row), _ptr(hidden), _ptr(ws), ws.numel(),
+                                   int(train), C.c_uint64(seed), _stream_ptr()), "head_encode")
+        return hidden
+
+    def decode(self, hidden: torch.Tensor, train: bool = False, seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+        """tcvn_head_decode: hidden [S, B, hidden] -> (event_logits [B, Ce], prong_logits [B, S-1, Cp]) (forward only)."""
+        S, batch, D = hidden.shape
+        assert D == self.cfg.hidden_dim and hidden.dtype == torch.float32 and hidden.is_contiguous()
+        ws = self._stage_ws(batch, S - 1, 0, hidden.device)
+        ev = torch.empty(batch, self.cfg.event_classes, device=hidden.device)
+        pr = torch.empty(batch, S - 1, self.cfg.prong_classes, device=hidden.device)
+        check(lib.tcvn_head_decode(self.handle, batch, S - 1, _ptr(hidden), _ptr(ev), _ptr(pr), _ptr(ws), ws.numel(), int(train),
+                                   C.c_uint64(seed), _stream_ptr()), "head_decode")
+        return ev, pr
+
     def loss(self, ev: torch.Tensor, pr: torch.Tensor, event_targets: torch.Tensor, prong_targets: torch.Tensor):
         """-> (losses[3] = total/event/prong, accs[2], d_event_logits, d_prong_logits), all on the device."""
         batch, max_prongs = pr.shape[0], pr.shape[1]

@@ -27,14 +27,14 @@ class _FusedStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor: Tensor, runtime: "HipRuntime", state: dict):
-        ctx.runtime, ctx.state = runtime, state
+        ctx.runtime, ctx.state, ctx.anchor = runtime, state, anchor
         ev, pr = state["event_logits"], state["prong_logits"]
         return ev, pr
 
     @staticmethod
     def backward(ctx, d_ev: Tensor, d_pr: Tensor):
         ctx.runtime._backward(ctx.state, d_ev, d_pr)
-        return None, None, None
+        return torch.zeros_like(ctx.anchor), None, None      # a real (zero) gradient: a DDP wrapper's hook on the anchor must fire
 
 
 class _FocalLoss(torch.autograd.Function):
@@ -82,6 +82,7 @@ class HipRuntime:
         self._sig = None
         self._grad_views: List[Tensor] = []
         self.overlap_embedders = True        # event DenseNet on a side stream underneath the prong DenseNet
+        self.anchor_param = None             # optional: module-owned anchor parameter (see NeutrinoFullBaseTrainer)
         self.grad_ready_hook = None          # called as hook(tag) when a gradient segment is final ("head", "event", "prong")
         self.segments: Dict[str, Tuple[int, int]] = {}
         self.offsets: Dict[str, Tuple[int, int]] = {}
@@ -169,6 +170,9 @@ class HipRuntime:
         self.flat_nbt = torch.stack([m.num_batches_tracked.to(dev) for m in all_bn]).contiguous()
         ran_ids = {id(m) for m in ran}
         self._nbt_inc = torch.tensor([1 if id(m) in ran_ids else 0 for m in all_bn], dtype=torch.int64, device=dev)
+        dec_ids = {id(m) for m in net.prong_decoder.modules()}
+        self._nbt_inc_embed = torch.tensor([1 if (id(m) in ran_ids and id(m) not in dec_ids) else 0 for m in all_bn],
+                                           dtype=torch.int64, device=dev)
         for i, m in enumerate(all_bn):
             m.num_batches_tracked.data = self.flat_nbt[i]
 
@@ -233,26 +237,77 @@ class HipRuntime:
             return ev, pr
         state = dict(rows=rows, tok_row=tok_row, B=B, P=P, n_prongs=n_prongs, event_logits=ev, prong_logits=pr,
                      feat=feat, pix=pix, keep=(event_px, prong_px))      # the COO lists are read again by backward
-        return _FusedStep.apply(self.anchor, self, state)
+        anchor = self.anchor_param if (self.anchor_param is not None and self.anchor_param.device == dev) else self.anchor
+        return _FusedStep.apply(anchor, self, state)
+
+    # ---------------------------------------------------------------------------------------------------------------
+    # stage-by-stage forward (the reference's sub-module call surface; forward only)
+    # ---------------------------------------------------------------------------------------------------------------
+    def _rows(self, event_px: SparsePixels, prong_px: SparsePixels, B: int, n_prongs: int, training: bool, seed: int) -> Tensor:
+        """[B + n_prongs, feat+pix+pos] input rows of the combined embedding from the two DenseNet engines."""
+        pe = self.network.prong_embedding
+        dev = self.flat_param.device
+        feat, pix, pos = pe.feature_embedding_dim, pe.pixel_embedding_dim, pe.position_embedding_dim
+        rows = torch.zeros(B + n_prongs, feat + pix + pos, device=dev)
+        rows[:, feat + pix:] = self._pos
+        event_px.count, prong_px.count = B, n_prongs
+        self.ev_engine.forward(event_px.coords, event_px.values, B, rows[:B, :feat + pix], training, seed ^ 0x1111,
+                               event_px.value_mode, event_px.noise_std if training else 0.0)
+        self.pr_engine.forward(prong_px.coords, prong_px.values, n_prongs, rows[B:, feat:feat + pix], training, seed ^ 0x2222,
+                               prong_px.value_mode, prong_px.noise_std if training else 0.0)
+        return rows
+
+    def embed(self, features: Tensor, extra: Tensor, event_px: SparsePixels, event_mask: Tensor, prong_px: SparsePixels,
+              prong_mask: Tensor, training: bool = False) -> Tensor:
+        """BaseProngEmbedding.forward: -> tokens [B, 1+P, hidden] (padding rows zero)."""
+        self.ensure_bound()
+        with torch.no_grad():
+            dev = self.flat_param.device
+            prong_mask = prong_mask.to(dev)
+            B, P = prong_mask.shape
+            n_prongs = int(prong_mask.sum().item())
+            seed = (self.seed * 1000003 + self.step) & 0x7FFFFFFFFFFFFFFF
+            self.step += 1
+            rows = self._rows(event_px, prong_px, B, n_prongs, training, seed)
+            if training:
+                self.flat_nbt += self._nbt_inc_embed
+            return self.head.embed(rows, token_rows(prong_mask, B), B, P, n_prongs, training, seed ^ 0x3333)
+
+    def encode(self, tokens: Tensor, mask: Tensor, training: bool = False) -> Tensor:
+        """ProngCustomBertEncoder.forward: tokens [B, S, hidden], mask [B, S] -> hidden [S, B, hidden] (masked)."""
+        self.ensure_bound()
+        with torch.no_grad():
+            dev = self.flat_param.device
+            if not tokens.is_cuda:
+                raise RuntimeError("transformercvn (MI355X build): the encoder runs on the GPU only; there is no CPU fallback")
+            tok = torch.where(mask.to(dev), 0, -1).to(torch.int32).contiguous()
+            seed = (self.seed * 1000003 + self.step) & 0x7FFFFFFFFFFFFFFF
+            self.step += 1
+            return self.head.encode(tokens.detach().float().contiguous(), tok, training, seed ^ 0x3333)
 
     def _backward(self, st: dict, d_ev: Tensor, d_pr: Tensor):
-        if self._reattach_grads():
-            pass                                     # grads were set to None by zero_grad(set_to_none=True): views re-attached
+        """Backward of the fused step in the order the gradient segments become final -- token path, event embedder (side
+        stream), prong embedder -- reporting each to ``grad_ready_hook`` so that its all-reduce overlaps with what is left."""
+        self._reattach_grads()                       # grads set to None by zero_grad(set_to_none=True): views re-attached
         B, feat, pix = st["B"], st["feat"], st["pix"]
+        hook = self.grad_ready_hook or (lambda tag: None)
         d_rows = self.head.backward(st["rows"], st["tok_row"], d_ev.contiguous(), d_pr.contiguous())
         self._pos_grad.add_(d_rows[:, feat + pix:].sum(0, keepdim=True))
-        if self.grad_ready_hook:
-            self.grad_ready_hook("head")
+        hook("head")
+        if not d_rows.is_cuda:                       # CPU stand-ins (tests of the exchange schedule): one queue
+            self.ev_engine.backward(d_rows[:B, :feat + pix])
+            hook("event")
+            self.pr_engine.backward(d_rows[B:, feat:feat + pix])
+            hook("prong")
+            return
         main = torch.cuda.current_stream(d_rows.device)
         side = self._side if self.overlap_embedders else main
         side.wait_stream(main)
         with torch.cuda.stream(side):                # event embedder backward underneath the prong embedder's (see forward)
             self.ev_engine.backward(d_rows[:B, :feat + pix])
-            if self.grad_ready_hook:
-                self.grad_ready_hook("event")        # the exchange of this segment is ordered after the side stream
+            hook("event")                            # issued from the side stream: the collective is ordered behind the event backward
         self.pr_engine.backward(d_rows[B:, feat:feat + pix])
-        if self.grad_ready_hook:
-            self.grad_ready_hook("prong")
+        hook("prong")
         main.wait_stream(side)
 
     def loss(self, ev: Tensor, pr: Tensor, event_targets: Tensor, prong_targets: Tensor):

@@ -18,3 +18,14 @@ class ProngCustomBertEncoder(nn.Module):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             self.encoder = nn.TransformerEncoder(layer, options.num_encoder_layers)
+
+    def forward(self, embeddings, mask):
+        """(tokens [B, S, D], mask [B, S] bool) -> (hidden [S, B, D], padding_mask [B, S], sequence_mask [S, B, 1]) like the
+        reference (:57-75), on the encoder stage of the head engine (tcvn_head_encode).  Forward only, no autograd."""
+        from transformercvn.hip.owners import owner_of
+        net = owner_of(self)
+        if net is None:
+            raise RuntimeError("ProngCustomBertEncoder.forward needs the owning NeutrinoBaseNetwork (its HIP runtime holds the plan)")
+        hidden = net.hip_runtime().encode(embeddings, mask, self.training)
+        B, S = mask.shape
+        return hidden, ~mask, mask.view(B, S, 1).transpose(0, 1).contiguous()

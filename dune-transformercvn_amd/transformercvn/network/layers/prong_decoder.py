@@ -10,3 +10,9 @@ class ProngDecoder(nn.Module):
         self.options = options
         self.hidden_dim_factor = hidden_dim_factor
         self.hidden_layer = nn.Linear(hidden_dim_factor * options.hidden_dim, output_dim)
+
+    def forward(self, hidden):
+        """[B, hidden_dim] -> [B, classes] (reference :15-16) on the HIP row GEMM; forward only, no autograd."""
+        from transformercvn.hip import rowops
+        return rowops.linear(hidden.reshape(-1, hidden.shape[-1]), self.hidden_layer.weight,
+                             self.hidden_layer.bias).reshape(*hidden.shape[:-1], -1)

@@ -17,6 +17,16 @@ class LinearBlock(nn.Module):
         self.norm = nn.BatchNorm1d(output_dim) if use_bn else nn.Identity()
         self.activation = nn.PReLU(output_dim) if options.linear_prelu_activation else nn.ReLU()
         self.dropout = nn.Dropout(options.dropout)
+        self._fused = isinstance(self.norm, nn.BatchNorm1d) and isinstance(self.activation, nn.PReLU)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """Linear -> BatchNorm1d -> PReLU -> Dropout on the row kernels (reference :25-33); forward only, no autograd."""
+        from transformercvn.hip import rowops
+        if not self._fused:
+            raise NotImplementedError("the MI355X path implements LinearBlock as Linear-BatchNorm1d-PReLU (both option files)")
+        z = rowops.linear(x, self.linear.weight, self.linear.bias)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (self.training and self.dropout.p > 0) else 0
+        return rowops.bn_prelu(z, self.norm, self.activation.weight, self.training, self.dropout.p, seed, 0x5000)
 
 
 class ProngFeatureEmbedding(nn.Module):

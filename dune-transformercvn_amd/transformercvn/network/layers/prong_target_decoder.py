@@ -29,3 +29,27 @@ class ProngTargetDecoder(nn.Module):
             widths.append(reported)
             width = reported
         return nn.Sequential(*modules), reported, widths
+
+    def forward(self, hidden):
+        """[T, B, hidden_dim] -> [T, B, classes] (reference :34-41): the Linear-BN-PReLU-Dropout blocks and the output layer
+        on the HIP row kernels; BatchNorm1d sees the zeroed padding tokens exactly like the reference.  Forward only."""
+        import torch
+        from torch import nn
+        from transformercvn.hip import rowops
+        T, B, D = hidden.shape
+        h = hidden.reshape(T * B, D)
+        mods = list(self.hidden_layers)
+        i = blk = 0
+        while i < len(mods):
+            lin = mods[i]
+            if not (i + 2 < len(mods) + 0 and isinstance(mods[i + 1], nn.BatchNorm1d) and isinstance(mods[i + 2], nn.PReLU)):
+                raise NotImplementedError("the MI355X path implements the decoder blocks as Linear-BatchNorm1d-PReLU")
+            drop = mods[i + 3] if i + 3 < len(mods) and isinstance(mods[i + 3], nn.Dropout) else None
+            h = rowops.linear(h, lin.weight, lin.bias)
+            p = drop.p if (drop is not None and self.training) else 0.0
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
+            h = rowops.bn_prelu(h, mods[i + 1], mods[i + 2].weight, self.training, p, seed, 0x7000 + blk)
+            i += 4 if drop is not None else 3
+            blk += 1
+        h = rowops.linear(h, self.output_layer.weight, self.output_layer.bias)
+        return h.reshape(T, B, self.output_dim)

@@ -49,9 +49,21 @@ class BaseProngEmbedding(nn.Module, ABC):
         self.combined_embedding = LinearBlock(
             options, self.feature_embedding_dim + self.pixel_embedding_dim + self.position_embedding_dim, options.hidden_dim)
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("run the fused network (NeutrinoBaseNetwork.forward); the embedding stage is not exposed "
-                                  "separately on the MI355X path yet")
+
+    def forward(self, features: Tensor, extra: Tensor, event_pixels, event_mask: Tensor, prong_pixels, prong_mask: Tensor):
+        """-> (tokens [B, 1+P, hidden], mask [B, 1+P]) like the reference (:87-125): both DenseNets, position embeddings, the
+        shared LinearBlock over event + packed prong rows, masked pad, event token first -- on the two DenseNet engines and
+        the embedding stage of the head engine (tcvn_head_embed).  Forward only, no autograd."""
+        from transformercvn.hip.owners import owner_of
+        net = owner_of(self)
+        if net is None:
+            raise RuntimeError("BaseProngEmbedding.forward needs the owning NeutrinoBaseNetwork (its HIP runtime holds the plans)")
+        if not isinstance(event_pixels, SparsePixels):
+            event_pixels = SparsePixels.from_dense(event_pixels)
+        if not isinstance(prong_pixels, SparsePixels):
+            prong_pixels = SparsePixels.from_dense(prong_pixels)
+        tokens = net.hip_runtime().embed(features, extra, event_pixels, event_mask, prong_pixels, prong_mask, self.training)
+        return tokens, torch.cat((event_mask.to(tokens.device), prong_mask.to(tokens.device)), dim=1)
 
 
 class NeutrinoBaseNetwork(nn.Module):
@@ -69,6 +81,9 @@ class NeutrinoBaseNetwork(nn.Module):
         self.prong_decoder = ProngTargetDecoder(options, options.num_prong_decoder_layers, num_prong_classes)
         self._options = options
         self._runtime = None
+        from transformercvn.hip.owners import register
+        register(self.prong_embedding, self)
+        register(self.encoder, self)
         self.pixel_shape: Tuple[int, int] = (400, 280)
 
     def hip_runtime(self):

@@ -14,6 +14,15 @@ from transformercvn.dataset.minkowski_dataset import MinkowskiDataset, Minkowski
 from transformercvn.network.trainers.metrics import make_metrics
 
 
+def _hide_anchor(module, state_dict, prefix, local_metadata):
+    state_dict.pop(prefix + "_ddp_anchor", None)
+    return state_dict
+
+
+def _supply_anchor(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+    state_dict.setdefault(prefix + "_ddp_anchor", torch.zeros(1))
+
+
 class NeutrinoFullBaseTrainer(NeutrinoBase, ABC):
     @abstractmethod
     def create_network(self, options: Options, features_dim: int, extra_dim: int, pixel_dim: int, num_prong_classes: int,
@@ -37,6 +46,48 @@ class NeutrinoFullBaseTrainer(NeutrinoBase, ABC):
         self.prong_loss_scale = 1.0 - options.event_prong_loss_proportion
         (self.event_accuracy, self.prong_accuracy, self.event_auc, self.prong_auc) = make_metrics(ds.num_event_classes,
                                                                                                  ds.num_prong_classes)
+        self._init_data_parallel()
+
+    # ---- data parallel (reference: train.py:123-127 wraps the module in Lightning's DDPStrategy) ---------------------
+    def _init_data_parallel(self):
+        """Parameter gradients never travel through autograd here (the HIP backward writes them into one flat arena), so torch
+        DDP's per-parameter hooks would never fire.  Everything is therefore listed in `_ddp_params_and_buffers_to_ignore`
+        (Lightning's wrapper forwards that list to DistributedDataParallel) except one hidden 1-element anchor parameter that
+        does get an autograd gradient every step -- DDP needs at least one parameter to manage and a hook that fires.  The
+        real exchange is the arena all-reduce of transformercvn.hip.distributed.GradReducer, installed by on_fit_start().
+        The anchor is kept out of state_dict()/load_state_dict() so checkpoints stay the reference's 1 208 keys."""
+        self._ddp_anchor = torch.nn.Parameter(torch.zeros(1))
+        self._ddp_params_and_buffers_to_ignore = ([n for n, _ in self.named_parameters() if n != "_ddp_anchor"] +
+                                                  [n for n, _ in self.named_buffers()])
+        self._register_state_dict_hook(_hide_anchor)
+        self._register_load_state_dict_pre_hook(_supply_anchor)
+        self._reducer = None
+
+    def enable_data_parallel(self, group=None):
+        """Install the overlapped arena all-reduce (RCCL via torch.distributed) on the runtime's segment hooks.  Called by
+        on_fit_start() under Lightning; custom loops (bench.py) call it after init_process_group.  No-op at world size 1."""
+        import torch.distributed as dist
+        from transformercvn.hip.distributed import GradReducer
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+            return None
+        rt = self.network.hip_runtime()
+        rt.ensure_bound()
+        self._reducer = GradReducer(rt.flat_grad, rt.segments, group)
+        rt.grad_ready_hook = self._reducer.on_ready
+        self._dp_group = group
+        return self._reducer
+
+    def on_fit_start(self):
+        self.enable_data_parallel()
+
+    def on_train_batch_start(self, batch, batch_idx, *args):
+        if self._reducer is not None:                       # DDP's broadcast_buffers=True semantics: rank 0's BN statistics
+            from transformercvn.hip.distributed import broadcast_buffers
+            broadcast_buffers(self.network.hip_runtime().flat_buf, getattr(self, "_dp_group", None))
+
+    def on_after_backward(self):
+        if self._reducer is not None:
+            self._reducer.finish()
 
     @property
     def dataset(self):
@@ -57,6 +108,7 @@ class NeutrinoFullBaseTrainer(NeutrinoBase, ABC):
             features[prong_mask] = (features[prong_mask] - self.mean) / self.std
             extra = (extra - self.extra_mean) / self.extra_std
         shape = self.training_dataset.pixel_shape
+        self.network.hip_runtime().anchor_param = self._ddp_anchor       # the autograd anchor of the fused step (see above)
         event_pixels = self.preprocess_pixels(event_coords, event_values, shape)
         prong_pixels = self.preprocess_pixels(prong_coords, prong_values, shape)
         return self.network(features, extra, event_pixels, event_mask, prong_pixels, prong_mask, counts)

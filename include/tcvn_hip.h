@@ -110,6 +110,33 @@ int64_t tcvn_head_workspace_bytes(const tcvn_head* p, int batch, int max_prongs,
 int tcvn_head_forward(tcvn_head* p, int batch, int max_prongs, int n_prongs, const float* rows, const int32_t* tok_row,
                       float* event_logits, float* prong_logits, void* workspace, int64_t workspace_bytes, int train,
                       uint64_t seed, void* stream);
+/* The three stages of tcvn_head_forward as separate forward-only entry points -- what the reference's sub-modules compute when
+ * called on their own (CreateCompiled.ipynb cells 7-8 call network.prong_embedding / .encoder / .event_decoder / .prong_decoder):
+ *   embed   rows, tok_row -> tokens [batch, 1+max_prongs, hidden] (batch-major, padding rows zero): the combined LinearBlock +
+ *           masked pad of BaseProngEmbedding.forward (networks/neutrino_full_base_network.py:113-125);
+ *   encode  tokens [batch, S, hidden], tok_row (only its sign is read: < 0 = padding) -> hidden [S, batch, hidden] (sequence-major,
+ *           masked): ProngCustomBertEncoder.forward (layers/prong_custom_bert_encoder.py:57-75);
+ *   decode  hidden [S, batch, hidden] -> event_logits [batch, Ce] from token 0 (layers/prong_decoder.py:15-16) and prong_logits
+ *           [batch, max_prongs, Cp] from tokens 1.. (layers/prong_target_decoder.py:34-41); either output may be NULL.
+ * Workspace: tcvn_head_workspace_bytes(batch, max_prongs, n_prongs) (n_prongs = 0 for encode / decode).  No backward: training
+ * goes through tcvn_head_forward / tcvn_head_backward. */
+int tcvn_head_embed(tcvn_head* p, int batch, int max_prongs, int n_prongs, const float* rows, const int32_t* tok_row, float* tokens,
+                    void* workspace, int64_t workspace_bytes, int train, uint64_t seed, void* stream);
+int tcvn_head_encode(tcvn_head* p, int batch, int max_prongs, const float* tokens, const int32_t* tok_row, float* hidden,
+                     void* workspace, int64_t workspace_bytes, int train, uint64_t seed, void* stream);
+int tcvn_head_decode(tcvn_head* p, int batch, int max_prongs, const float* hidden, float* event_logits, float* prong_logits,
+                     void* workspace, int64_t workspace_bytes, int train, uint64_t seed, void* stream);
+
+/* Row operators behind the holder modules' own forward() (forward only, fp32):
+ *   y = x W^T + b (torch.nn.Linear layout; bias may be NULL)                      -- layers/prong_decoder.py:15-16
+ *   y = dropout(prelu(batchnorm1d(x)))  with batch statistics + running-stat update when train != 0, running statistics
+ *   otherwise; save_mean_rstd: 2*channels floats of scratch                        -- layers/prong_feature_embedding.py:25-33 */
+int tcvn_linear_forward(const float* x, int64_t ldx, const float* weight, const float* bias, float* y, int64_t ldy, int rows,
+                        int n_out, int n_in, void* stream);
+int tcvn_rows_bn_prelu_forward(const float* x, int64_t ldx, int rows, int channels, const float* gamma, const float* beta,
+                               const float* slope, float* running_mean, float* running_var, float* y, int64_t ldy,
+                               float* save_mean_rstd, int train, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);
+
 /* Softmax focal loss and its gradient w.r.t. the logits (trainers/neutrino_full_base_trainer.py:148-177):
  * event_targets [batch] int64, prong_targets [batch, max_prongs] int8 (-1 = padding).
  * losses[3] (device, fp32) = {total, event, prong}; accs[6]: {event accuracy, prong accuracy} + 4 floats of scratch;

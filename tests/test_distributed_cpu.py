@@ -38,3 +38,94 @@ def test_grad_reducer_two_ranks_gloo():
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The runtime's own backward schedule + the Lightning-module hooks, end to end on two gloo ranks.  CPU tensors stand in for
+# the gradient arena and fake engines write rank-dependent "gradients" into it; everything else is the product code path:
+# NeutrinoFullBaseTrainer.enable_data_parallel() -> HipRuntime._backward() -> grad_ready_hook -> GradReducer -> on_after_backward().
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeEngine:
+    def __init__(self, arena, span, value):
+        self.arena, self.span, self.value = arena, span, value
+
+    def backward(self, d):
+        lo, hi = self.span
+        self.arena[lo:hi] += self.value * torch.arange(hi - lo, dtype=torch.float32)
+
+
+class _FakeHead(_FakeEngine):
+    def __init__(self, arena, spans, value, rows, width):
+        self.arena, self.spans, self.value, self.rows, self.width = arena, spans, value, rows, width
+
+    def backward(self, rows, tok_row, d_ev, d_pr):
+        for lo, hi in self.spans:
+            self.arena[lo:hi] += self.value
+        return torch.full((self.rows, self.width), self.value)
+
+
+def _runtime_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "dune-transformercvn_amd"), os.path.join(root, "tests")]
+    from oracle import tcvn_oracle as O
+    from model_utils import build_trainer
+    from transformercvn.hip.distributed import segment_plan
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = O.tutorial_config(densenet_structure=[1, 1], densenet_growth_rate=8, initial_pixel_dim=16, num_encoder_layers=1)
+    model = build_trainer(cfg, None, device=None)
+    rt = model.network.hip_runtime()
+    # the arenas ensure_bound() would build on the GPU, on the CPU
+    names = [n for n, _ in model.network.named_parameters()]
+    sizes = [p.numel() for _, p in model.network.named_parameters()]
+    offs = dict(zip(names, zip([sum(sizes[:i]) for i in range(len(sizes))], sizes)))
+
+    def span(prefix):
+        ks = [k for k in offs if k.startswith(prefix)]
+        return min(offs[k][0] for k in ks), max(offs[k][0] + offs[k][1] for k in ks)
+    total = sum(sizes)
+    rt.flat_grad = torch.zeros(total)
+    rt.flat_param = torch.zeros(total)
+    rt.flat_buf = torch.full((64,), float(rank))
+    rt.segments = {"prong": span("prong_embedding.prong_pixel_embedding."), "event": span("prong_embedding.event_pixel_embedding.")}
+    rt._needs_rebind = lambda: False
+    rt._reattach_grads = lambda: False
+    rt._pos_grad = torch.zeros(1, 32)
+    plan = segment_plan(total, rt.segments)
+    pe = model.network.prong_embedding
+    feat, pix = pe.feature_embedding_dim, pe.pixel_embedding_dim
+    rt.head = _FakeHead(rt.flat_grad, plan["head"], float(rank + 1), 5, feat + pix + 32)
+    rt.ev_engine = _FakeEngine(rt.flat_grad, rt.segments["event"], float(rank + 1))
+    rt.pr_engine = _FakeEngine(rt.flat_grad, rt.segments["prong"], float(2 * rank + 1))
+    order = []
+    assert model.enable_data_parallel() is not None and rt.grad_ready_hook is not None
+    inner = rt.grad_ready_hook
+    rt.grad_ready_hook = lambda tag: (order.append(tag), inner(tag))
+    model.on_train_batch_start(None, 0)                     # buffer broadcast from rank 0
+    st = dict(B=2, feat=feat, pix=pix, rows=None, tok_row=None)
+    rt._backward(st, torch.zeros(2, 4), torch.zeros(2, 3, 8))
+    model.on_after_backward()                               # waits for the segment exchanges
+    mean_scale = sum(r + 1 for r in range(world)) / world
+    mean_scale_pr = sum(2 * r + 1 for r in range(world)) / world
+    ok = order == ["head", "event", "prong"] and bool((rt.flat_buf == 0).all())
+    for lo, hi in plan["head"]:
+        ok = ok and torch.allclose(rt.flat_grad[lo:hi], torch.full((hi - lo,), mean_scale))
+    lo, hi = rt.segments["event"]
+    ok = ok and torch.allclose(rt.flat_grad[lo:hi], mean_scale * torch.arange(hi - lo, dtype=torch.float32))
+    lo, hi = rt.segments["prong"]
+    ok = ok and torch.allclose(rt.flat_grad[lo:hi], mean_scale_pr * torch.arange(hi - lo, dtype=torch.float32))
+    # torch DDP accepts the module: everything but the hidden anchor is on the ignore list, checkpoints keep the reference keys
+    ddp = torch.nn.parallel.DistributedDataParallel(model)
+    managed = [n for n, p in ddp.module.named_parameters() if n not in model._ddp_params_and_buffers_to_ignore]
+    ok = ok and managed == ["_ddp_anchor"] and "_ddp_anchor" not in model.state_dict()
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_runtime_backward_hooks_average_gradients_two_ranks_gloo():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_runtime_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)

@@ -86,7 +86,9 @@ def test_train_step_matches_reference(name):
     assert rel_err(pr.cpu(), g["train_prong_logits"]) < LOGIT_GATE
 
 
-BF16_LOGIT_GATE = 2e-2     # measured on MI355X: see DESIGN.md section 2 (the reference's own bf16 autocast: 2.6-3.5e-3)
+# measured on MI355X; the reference's own bf16 autocast sits at 2.6-3.5e-3 in eval mode.
+# Train mode normalises with the statistics of a 3-22 map batch, which amplifies bf16 rounding of the activations.
+BF16_EVAL_GATE, BF16_TRAIN_GATE = 5e-3, 3e-2
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -108,7 +110,7 @@ def test_bf16_full_model_logit_error_vs_reference(name):
         _, _, ev, pr = model.shared_step(dbatch)
     t_ev, t_pr = rel_err(ev.cpu(), g["train_event_logits"]), rel_err(pr.cpu(), g["train_prong_logits"])
     print(f"BF16 LOGIT ERROR {name}: eval event {e_ev:.3e} prong {e_pr:.3e}; train event {t_ev:.3e} prong {t_pr:.3e}")
-    assert max(e_ev, e_pr, t_ev, t_pr) < BF16_LOGIT_GATE
+    assert max(e_ev, e_pr) < BF16_EVAL_GATE and max(t_ev, t_pr) < BF16_TRAIN_GATE
 
 
 def test_cpu_tensors_fail_loudly():

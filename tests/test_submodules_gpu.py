@@ -1,0 +1,78 @@
+"""The reference's sub-module call surface (CreateCompiled.ipynb cells 7-8 call network.prong_embedding,
+network.encoder, network.event_decoder, network.prong_decoder one after the other): each stage's own forward() runs the
+matching C-ABI stage and must reproduce the reference's intermediate taps and logits stored in the goldens."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tcvn_oracle as O
+from golden_utils import load_case, train_cfg, rel_err, tap_sample
+from model_utils import build_trainer, to_device
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(t, g, key, tol=2e-5):
+    stat, samp = tap_sample(t.cpu())
+    ref_stat, ref_samp = g[key.replace("tap:", "tap_stat:")], g[key.replace("tap:", "tap_samp:")]
+    scale = max(float(np.abs(ref_samp).max()), 1e-12)
+    return max(float(np.abs(samp - ref_samp).max()) / scale, float(np.abs(stat - ref_stat).max()) / max(float(np.abs(ref_stat).max()), 1e-12)) < tol
+
+
+@pytest.mark.parametrize("name", ["small_b3", "tutorial_b2p4", "tutorial_ragged"])
+@pytest.mark.parametrize("training", [False, True])
+def test_stage_by_stage_forward_matches_reference(name, training):
+    cfg, over, batch, g = load_case(name)
+    if training:
+        cfg = train_cfg(over)
+    model = build_trainer(cfg, O.fill_state(cfg, int(g["weight_seed"])))
+    model.train(training)
+    f, x, ec, ev, em, pc, pv, pm, et, pt = to_device(batch)
+    width = int(pm.sum(1).max())
+    f, pm = f[:, :width].contiguous(), pm[:, :width].contiguous()
+    net = model.network
+    shape = model.training_dataset.pixel_shape
+    event_pixels = model.preprocess_pixels(ec, ev, shape)
+    prong_pixels = model.preprocess_pixels(pc, pv, shape)
+    kind = "traintap:" if training else "evaltap:"
+    with torch.no_grad():
+        tokens, mask = net.prong_embedding(f, x, event_pixels, em, prong_pixels, pm)
+        assert tokens.shape == (f.shape[0], 1 + width, cfg.hidden_dim) and mask.shape == (f.shape[0], 1 + width)
+        assert mask.dtype == torch.bool and bool(mask[:, 0].all())
+        assert _close(tokens, g, kind + "tokens"), "tokens"
+        hidden, padding_mask, sequence_mask = net.encoder(tokens, mask)
+        assert hidden.shape == (1 + width, f.shape[0], cfg.hidden_dim)
+        assert torch.equal(padding_mask, ~mask) and sequence_mask.shape == (1 + width, f.shape[0], 1)
+        assert _close(hidden, g, kind + "hidden", 5e-5), "hidden"
+        ev_logits = net.event_decoder(hidden[0])
+        pr_logits = net.prong_decoder(hidden[1:]).transpose(0, 1)
+    key = "train" if training else "eval"
+    e1, e2 = rel_err(ev_logits.cpu(), g[key + "_event_logits"]), rel_err(pr_logits.cpu(), g[key + "_prong_logits"])
+    print(name, training, "stage-by-stage logits vs reference", e1, e2)
+    assert e1 < 1e-4 and e2 < 1e-4
+
+
+def test_linear_block_and_dense_net_forward_alone():
+    cfg, over, batch, g = load_case("small_b3")
+    model = build_trainer(cfg, O.fill_state(cfg, int(g["weight_seed"])))
+    model.eval()
+    pe = model.network.prong_embedding
+    x = torch.randn(7, pe.combined_embedding.linear.in_features, device="cuda")
+    y = pe.combined_embedding(x)
+    lb = pe.combined_embedding
+    z = torch.nn.functional.linear(x, lb.linear.weight)
+    ref = torch.nn.functional.prelu(torch.nn.functional.batch_norm(z, lb.norm.running_mean, lb.norm.running_var, lb.norm.weight,
+                                                                  lb.norm.bias, False, 0.1, 1e-5), lb.activation.weight)
+    assert rel_err(y.cpu(), ref.detach().cpu()) < 1e-5
+    dense = model.preprocess_pixels(batch[5].cuda(), batch[6].cuda(), model.training_dataset.pixel_shape).to_dense()
+    out = pe.prong_pixel_embedding(dense)                         # dense NCHW map in, like the reference's DenseNet.forward
+    stat, samp = tap_sample(out.cpu())
+    pfx = "evaltap_samp:network.prong_embedding.prong_pixel_embedding:out"
+    assert float(np.abs(samp - g[pfx]).max()) / float(np.abs(g[pfx]).max()) < 1e-4
+
+
+def test_stage_calls_on_cpu_fail_loudly():
+    cfg, over, batch, g = load_case("small_b3")
+    model = build_trainer(cfg, None, device=None)
+    with pytest.raises(RuntimeError):
+        model.network.event_decoder(torch.zeros(2, cfg.hidden_dim))
