@@ -113,7 +113,7 @@ class NeutrinoBase(_Base):
             print(f"Unable to load desired optimizer: {o.optimizer}.\nUsing pytorch AdamW as a default.")
             opt_cls = torch.optim.AdamW
         no_decay = ("bias", "LayerNorm.weight")
-        named = list(self.named_parameters())
+        named = [(n, p) for n, p in self.named_parameters() if n != "_ddp_anchor"]     # the DDP anchor is not a model parameter
         groups = [{"params": [p for n, p in named if not any(s in n for s in no_decay)], "weight_decay": o.l2_penalty},
                   {"params": [p for n, p in named if any(s in n for s in no_decay)], "weight_decay": 0.0}]
         optimizer = None
