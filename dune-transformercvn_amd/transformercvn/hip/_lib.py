@@ -26,6 +26,11 @@ class DenseNetCfg(C.Structure):
                 ("mode", C.c_int)]
 
 
+class SdxlCfg(C.Structure):
+    _fields_ = [("in_ch", C.c_int), ("out_dim", C.c_int), ("init_ch", C.c_int), ("repeat", C.c_int), ("num_blocks", C.c_int),
+                ("H", C.c_int), ("W", C.c_int), ("mode", C.c_int)]
+
+
 class HeadCfg(C.Structure):
     _fields_ = [("hidden_dim", C.c_int), ("heads", C.c_int), ("n_layers", C.c_int), ("in_dim", C.c_int),
                 ("event_classes", C.c_int), ("prong_classes", C.c_int), ("n_dec", C.c_int), ("dec_dims", C.c_int * 8),
@@ -58,6 +63,15 @@ def _load():
     sig("tcvn_densenet_forward", i32, vp, i32, vp, vp, i64, i32, f32, vp, i64, vp, i64, i32, u64, vp)
     sig("tcvn_densenet_backward", i32, vp, i32, vp, i64, vp, i64, vp)
     sig("tcvn_densenet_tap", i32, vp, i32, C.c_char_p, P(i64), P(i32), P(i32), P(i32), P(i32), P(i32), P(i32))
+    sig("tcvn_sdxl_create", i32, P(SdxlCfg), P(vp))
+    sig("tcvn_sdxl_destroy", None, vp)
+    sig("tcvn_sdxl_num_slots", i32, vp)
+    sig("tcvn_sdxl_slot", i32, vp, i32, C.c_char_p, i32, P(i64), P(i32))
+    sig("tcvn_sdxl_bind", i32, vp, P(vp), P(vp))
+    sig("tcvn_sdxl_workspace_bytes", i64, vp, i32, i32)
+    sig("tcvn_sdxl_forward", i32, vp, i32, vp, vp, i64, i32, f32, vp, i64, vp, i64, i32, u64, vp)
+    sig("tcvn_sdxl_backward", i32, vp, i32, vp, i64, vp, i64, vp)
+    sig("tcvn_sdxl_tap", i32, vp, i32, C.c_char_p, P(i64), P(i32), P(i32), P(i32), P(i32), P(i32), P(i32))
     sig("tcvn_head_create", i32, P(HeadCfg), P(vp))
     sig("tcvn_head_destroy", None, vp)
     sig("tcvn_head_num_slots", i32, vp)
@@ -99,7 +113,8 @@ def profile_records():
 EXPORTS = [
     "tcvn_grad_sumsq", "tcvn_adamw_step", "tcvn_backward_overlap", "tcvn_profile_enable", "tcvn_profile_filter", "tcvn_profile_reset", "tcvn_profile_count", "tcvn_profile_get",
     "tcvn_focal_loss", "tcvn_dropout_keep", "tcvn_head_embed", "tcvn_head_encode", "tcvn_head_decode", "tcvn_linear_forward",
-    "tcvn_rows_bn_prelu_forward",
+    "tcvn_rows_bn_prelu_forward", "tcvn_sdxl_create", "tcvn_sdxl_destroy", "tcvn_sdxl_num_slots", "tcvn_sdxl_slot", "tcvn_sdxl_bind",
+    "tcvn_sdxl_workspace_bytes", "tcvn_sdxl_forward", "tcvn_sdxl_backward", "tcvn_sdxl_tap",
     "tcvn_version", "tcvn_densenet_create", "tcvn_densenet_destroy", "tcvn_densenet_num_slots", "tcvn_densenet_slot",
     "tcvn_densenet_bind", "tcvn_densenet_workspace_bytes", "tcvn_densenet_forward", "tcvn_densenet_backward",
     "tcvn_densenet_tap", "tcvn_head_create", "tcvn_head_destroy", "tcvn_head_num_slots", "tcvn_head_slot", "tcvn_head_bind",

@@ -78,7 +78,46 @@ class _Plan:
             pass
 
 
-class DenseNetEngine(_Plan):
+class _EmbedderEngine(_Plan):
+    """Shared driver of the two pixel-map embedder plans (tcvn_densenet_* / tcvn_sdxl_*: same calling convention)."""
+    out_dim = 0
+
+    def __init__(self):
+        super().__init__()
+        self._n = 0
+
+    def workspace_bytes(self, n_img: int, with_backward: bool) -> int:
+        return self._fn("workspace_bytes")(self.handle, n_img, int(with_backward))
+
+    def forward(self, coords: torch.Tensor, values: torch.Tensor, n_img: int, out: torch.Tensor, train: bool, seed: int = 0,
+                log_pixels: bool = False, noise_std: float = 0.0):
+        """coords int32 [nnz,3], values fp32 [nnz,C]; out: fp32 2-d view with row stride out.stride(0)."""
+        assert coords.dtype == torch.int32 and coords.is_contiguous() and values.dtype == torch.float32 and values.is_contiguous()
+        assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape == (n_img, self.out_dim)
+        ws = self.workspace(self.workspace_bytes(n_img, train), coords.device)
+        self._n = n_img
+        self._inputs = (coords, values)          # backward reads the COO list again (sparse stem weight gradient)
+        check(self._fn("forward")(self.handle, n_img, _ptr(coords), _ptr(values), coords.shape[0], int(log_pixels),
+                                  float(noise_std), _ptr(out), out.stride(0), _ptr(ws), ws.numel(), int(train),
+                                  C.c_uint64(seed), _stream_ptr()), f"{self._prefix}_forward")
+
+    def backward(self, d_out: torch.Tensor):
+        assert d_out.dtype == torch.float32 and d_out.stride(1) == 1 and d_out.shape == (self._n, self.out_dim)
+        ws = self._ws
+        check(self._fn("backward")(self.handle, self._n, _ptr(d_out), d_out.stride(0), _ptr(ws), ws.numel(), _stream_ptr()),
+              f"{self._prefix}_backward")
+
+    def tap(self, name: str) -> torch.Tensor:
+        """NHWC view [n,h,w,c] of an intermediate of the last forward (validation only)."""
+        off, n, h, w, c, ld, es = C.c_int64(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(self._fn("tap")(self.handle, self._n, name.encode(), C.byref(off), C.byref(n), C.byref(h), C.byref(w),
+                              C.byref(c), C.byref(ld), C.byref(es)), f"tap {name}")
+        dt = {8: torch.float64, 4: torch.float32}.get(es.value, torch.bfloat16)
+        raw = self._ws[off.value: off.value + n.value * h.value * w.value * ld.value * es.value].view(dt)
+        return raw.view(n.value, h.value, w.value, ld.value)[..., :c.value]
+
+
+class DenseNetEngine(_EmbedderEngine):
     _prefix = "densenet"
 
     def __init__(self, in_ch: int, out_dim: int, init_ch: int, growth: int, bn_size: int, layers, H: int, W: int,
@@ -94,37 +133,21 @@ class DenseNetEngine(_Plan):
         self.mode = mode
         self.out_dim = out_dim
         check(lib.tcvn_densenet_create(C.byref(cfg), C.byref(self.handle)), "densenet_create")
-        self._n = 0
 
-    def workspace_bytes(self, n_img: int, with_backward: bool) -> int:
-        return lib.tcvn_densenet_workspace_bytes(self.handle, n_img, int(with_backward))
 
-    def forward(self, coords: torch.Tensor, values: torch.Tensor, n_img: int, out: torch.Tensor, train: bool, seed: int = 0,
-                log_pixels: bool = False, noise_std: float = 0.0):
-        """coords int32 [nnz,3], values fp32 [nnz,C]; out: fp32 2-d view with row stride out.stride(0)."""
-        assert coords.dtype == torch.int32 and coords.is_contiguous() and values.dtype == torch.float32 and values.is_contiguous()
-        assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape == (n_img, self.out_dim)
-        ws = self.workspace(self.workspace_bytes(n_img, train), coords.device)
-        self._n = n_img
-        self._inputs = (coords, values)          # backward reads the COO list again (sparse stem weight gradient)
-        check(lib.tcvn_densenet_forward(self.handle, n_img, _ptr(coords), _ptr(values), coords.shape[0], int(log_pixels),
-                                        float(noise_std), _ptr(out), out.stride(0), _ptr(ws), ws.numel(), int(train),
-                                        C.c_uint64(seed), _stream_ptr()), "densenet_forward")
+class SdxlEngine(_EmbedderEngine):
+    """SDXL-style embedder plan (tcvn_sdxl_* in include/tcvn_hip.h; parity unpinned, see oracle/sdxl_oracle.py)."""
+    _prefix = "sdxl"
 
-    def backward(self, d_out: torch.Tensor):
-        assert d_out.dtype == torch.float32 and d_out.stride(1) == 1 and d_out.shape == (self._n, self.out_dim)
-        ws = self._ws
-        check(lib.tcvn_densenet_backward(self.handle, self._n, _ptr(d_out), d_out.stride(0), _ptr(ws), ws.numel(),
-                                         _stream_ptr()), "densenet_backward")
-
-    def tap(self, name: str) -> torch.Tensor:
-        """NHWC view [n,h,w,c] of an intermediate of the last forward (validation only)."""
-        off, n, h, w, c, ld, es = C.c_int64(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        check(lib.tcvn_densenet_tap(self.handle, self._n, name.encode(), C.byref(off), C.byref(n), C.byref(h), C.byref(w),
-                                    C.byref(c), C.byref(ld), C.byref(es)), f"tap {name}")
-        dt = {8: torch.float64, 4: torch.float32}.get(es.value, torch.bfloat16)
-        raw = self._ws[off.value: off.value + n.value * h.value * w.value * ld.value * es.value].view(dt)
-        return raw.view(n.value, h.value, w.value, ld.value)[..., :c.value]
+    def __init__(self, in_ch: int, out_dim: int, init_ch: int, repeat: int, num_blocks: int, H: int, W: int, mode: int):
+        super().__init__()
+        cfg = _lib.SdxlCfg()
+        cfg.in_ch, cfg.out_dim, cfg.init_ch, cfg.repeat, cfg.num_blocks = in_ch, out_dim, init_ch, repeat, num_blocks
+        cfg.H, cfg.W, cfg.mode = H, W, mode
+        self.cfg = cfg
+        self.mode = mode
+        self.out_dim = out_dim
+        check(lib.tcvn_sdxl_create(C.byref(cfg), C.byref(self.handle)), "sdxl_create")
 
 
 class HeadEngine(_Plan):

@@ -80,6 +80,39 @@ int tcvn_densenet_tap(const tcvn_densenet* p, int n_img, const char* name, int64
                       int* c, int* ld, int* elem_bytes);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * SDXL-style embedder (replaces transformercvn/network/layers/sdxl_net.py:7-42 SDXLNet.forward and its autograd: the
+ * diffusers VAE Encoder with block_out_channels [d,d,2d,2d,4d,4d,8d,8d,out], GroupNorm with one group, SiLU, stride-2
+ * downsampling with (0,1,0,1) padding, one-token mid-block attention, then Flatten + Linear(out,out); selected by
+ * networks/neutrino_full_sdxl_network.py:6-20).  Same calling convention as the DenseNet embedder.  Parity is UNPINNED:
+ * diffusers is neither vendored nor pinned by the reference; oracle/sdxl_oracle.py restates the definitions.
+ * --------------------------------------------------------------------------------------------------------------- */
+typedef struct tcvn_sdxl_cfg {
+    int in_ch;          /* pixel channels (3)                                                   */
+    int out_dim;        /* embedding width (256 prong / 288 event) = last block's channel count */
+    int init_ch;        /* options.initial_pixel_dim (64)                                       */
+    int repeat;         /* repeat_block_dim (2)                                                 */
+    int num_blocks;     /* num_blocks (4): widths d, 2d, 4d, 8d, each `repeat` times            */
+    int H, W;           /* pixel map shape (400, 280); must reduce to 1x1                       */
+    int mode;           /* TCVN_MODE_*                                                          */
+} tcvn_sdxl_cfg;
+typedef struct tcvn_sdxl tcvn_sdxl;
+int tcvn_sdxl_create(const tcvn_sdxl_cfg* cfg, tcvn_sdxl** out);
+void tcvn_sdxl_destroy(tcvn_sdxl* p);
+/* slots in state_dict order, names relative to the SDXLNet module ("encoder.conv_in.weight", ..., "output_layer.1.bias") */
+int tcvn_sdxl_num_slots(const tcvn_sdxl* p);
+int tcvn_sdxl_slot(const tcvn_sdxl* p, int i, char* name, int name_cap, int64_t* numel, int* kind);
+int tcvn_sdxl_bind(tcvn_sdxl* p, void* const* data, void* const* grad);
+int64_t tcvn_sdxl_workspace_bytes(const tcvn_sdxl* p, int n_img, int with_backward);
+int tcvn_sdxl_forward(tcvn_sdxl* p, int n_img, const int32_t* coords, const float* values, int64_t nnz, int log_pixels,
+                      float noise_std, float* out, int64_t out_ld, void* workspace, int64_t workspace_bytes, int train,
+                      uint64_t seed, void* stream);
+int tcvn_sdxl_backward(tcvn_sdxl* p, int n_img, const float* d_out, int64_t d_out_ld, void* workspace, int64_t workspace_bytes,
+                       void* stream);
+/* taps: "img", "conv_in", "block<i>" (output of down block i in front of its downsampler), "mid" */
+int tcvn_sdxl_tap(const tcvn_sdxl* p, int n_img, const char* name, int64_t* byte_off, int* n, int* h, int* w, int* c, int* ld,
+                  int* elem_bytes);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Token path: combined embedding, transformer encoder, decoders, focal loss
  * (networks/neutrino_full_base_network.py:99-125,184-188; layers/prong_custom_bert_encoder.py:57-75;
  *  layers/prong_decoder.py:15-16; layers/prong_target_decoder.py:34-41; trainers/neutrino_full_base_trainer.py:148-177)

@@ -182,8 +182,13 @@ def state_layout(cfg) -> Dict[str, Tuple[int, ...]]:
     for j, (i, o) in enumerate(feature_embedding_dims(cfg, feat)):
         _linear_block_layout(f"{pe}.feature_embedding.embedding.{j}", cfg, i, o, out)
     in_ch = cfg.pixel_dim * 256 if cfg.one_hot_pixels else cfg.pixel_dim
-    densenet_layout(pe + ".prong_pixel_embedding", cfg, in_ch, pix, out)
-    densenet_layout(pe + ".event_pixel_embedding", cfg, in_ch, pix + feat, out)
+    if getattr(cfg, "embedder", "dense") == "sdxl":              # networks/neutrino_full_sdxl_network.py:6-15 (parity unpinned)
+        from oracle.sdxl_oracle import sdxl_layout
+        sdxl_layout(pe + ".prong_pixel_embedding", in_ch, pix, cfg.initial_pixel_dim, out)
+        sdxl_layout(pe + ".event_pixel_embedding", in_ch, pix + feat, cfg.initial_pixel_dim, out)
+    else:
+        densenet_layout(pe + ".prong_pixel_embedding", cfg, in_ch, pix, out)
+        densenet_layout(pe + ".event_pixel_embedding", cfg, in_ch, pix + feat, out)
     _linear_block_layout(pe + ".combined_embedding", cfg, feat + pix + pos, cfg.hidden_dim, out)
     d = cfg.hidden_dim
     for l in range(cfg.num_encoder_layers):
@@ -460,7 +465,12 @@ def prong_embedding_forward(sd, cfg, features, extra, event_pixels, event_mask, 
     pe = "network.prong_embedding"
     B, P, _ = features.shape
     pix, feat, pos = embed_dims(cfg)
-    ev = densenet_forward(sd, pe + ".event_pixel_embedding", cfg, event_pixels, ctx)
+    if getattr(cfg, "embedder", "dense") == "sdxl":
+        from oracle.sdxl_oracle import sdxl_forward
+        embed = lambda prefix, px: sdxl_forward(sd, prefix, px, ctx.taps)
+    else:
+        embed = lambda prefix, px: densenet_forward(sd, prefix, cfg, px, ctx)
+    ev = embed(pe + ".event_pixel_embedding", event_pixels)
     ev = torch.cat((ev, sd[pe + ".event_position_embedding"].expand(B, -1)), dim=1)
     I1, I2 = pack_indices(prong_mask)
     packed = features[I1, I2]
@@ -470,7 +480,7 @@ def prong_embedding_forward(sd, cfg, features, extra, event_pixels, event_mask, 
         fe = torch.cat([packed, extra[I1]], dim=1)
         for j in range(len(feature_embedding_dims(cfg, feat))):
             fe = linear_block(sd, f"{pe}.feature_embedding.embedding.{j}", cfg, fe, ctx)
-    pp = densenet_forward(sd, pe + ".prong_pixel_embedding", cfg, prong_pixels, ctx)
+    pp = embed(pe + ".prong_pixel_embedding", prong_pixels)
     # quirk: prongs also receive the *event* position embedding (neutrino_full_base_network.py:107)
     pr = torch.cat((fe, pp, sd[pe + ".event_position_embedding"].expand(pp.shape[0], -1)), dim=1)
     comb = linear_block(sd, pe + ".combined_embedding", cfg, torch.cat((ev, pr), dim=0), ctx)

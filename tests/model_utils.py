@@ -5,6 +5,8 @@ import torch
 def build_trainer(cfg, state=None, precision="fp32", device="cuda", train_file="synthetic:16:4"):
     from transformercvn.options import Options
     from transformercvn.network.trainers.neutrino_full_dense_trainer import NeutrinoFullDenseTrainer
+    if getattr(cfg, "embedder", "dense") == "sdxl":
+        from transformercvn.network.trainers.neutrino_full_sdxl_trainer import NeutrinoFullSDXLTrainer as NeutrinoFullDenseTrainer
     o = Options()
     o.update_options({k: v for k, v in vars(cfg).items() if k in vars(o)})
     o.training_file = train_file

@@ -12,7 +12,7 @@ import torch
 from oracle import tcvn_oracle as O
 from golden_utils import load_case, train_cfg, rel_err
 from model_utils import build_trainer, to_device
-from test_oracle_golden import grad_close
+from test_oracle_golden import grad_close, is_noise_grad
 
 pytestmark = pytest.mark.gpu
 

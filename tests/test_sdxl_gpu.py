@@ -1,0 +1,110 @@
+"""SDXL-style embedder (BASELINE config 4; reference: layers/sdxl_net.py:7-42) on the MI355X against the CPU restatement in
+oracle/sdxl_oracle.py.  PARITY UNPINNED: the arithmetic lives in an un-vendored, un-pinned `diffusers`, so these
+tests establish oracle <-> HIP self-consistency plus the shape facts the reference fixes ([N,3,400,280] -> [N,out] through a
+1x1 final map); they are not reference parity."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tcvn_oracle as O
+from oracle import sdxl_oracle as S
+from golden_utils import rel_err
+from model_utils import build_trainer, to_device
+
+pytestmark = pytest.mark.gpu
+
+PFX = "network.prong_embedding.prong_pixel_embedding"
+
+
+def _cfg(**over):
+    base = dict(embedder="sdxl", initial_pixel_dim=8, pixel_embedding_dim=64, hidden_dim=64, num_encoder_layers=2,
+                num_prong_decoder_layers=3, dropout=0.0, pixel_noise_std=0.0)
+    base.update(over)
+    return O.tutorial_config(**base)
+
+
+def _engine(cfg, sd, mode, with_grad):
+    from transformercvn.hip.engine import SdxlEngine
+    pix, feat, pos = O.embed_dims(cfg)
+    eng = SdxlEngine(cfg.pixel_dim, pix, cfg.initial_pixel_dim, 2, 4, cfg.pixel_shape[0], cfg.pixel_shape[1], mode)
+    data = {k[len(PFX) + 1:]: v.cuda().contiguous() for k, v in sd.items() if k.startswith(PFX + ".")}
+    grads = {k: torch.zeros_like(v) for k, v in data.items()} if with_grad else None
+    eng.bind(data, grads)
+    return eng, data, grads
+
+
+def _oracle(cfg, sd, batch, d_out=None, dtype=torch.float64):
+    sdd = {k: v.to(dtype).requires_grad_(d_out is not None) for k, v in sd.items() if k.startswith(PFX + ".")}
+    taps = {}
+    px = O.preprocess_pixels(cfg, batch[5], batch[6].to(dtype), False)
+    out = S.sdxl_forward(sdd, PFX, px, taps)
+    grads = None
+    if d_out is not None:
+        gs = torch.autograd.grad(out, list(sdd.values()), d_out.to(dtype), allow_unused=True)
+        grads = {k[len(PFX) + 1:]: (g if g is not None else torch.zeros_like(v)) for (k, v), g in zip(sdd.items(), gs)}
+    return out.detach(), {k: v.detach() for k, v in taps.items()}, grads
+
+
+@pytest.mark.parametrize("mode,tol,gtol", [(0, 2e-4, 2e-3), (1, 5e-2, 1.5e-1)])
+def test_sdxl_embedder_forward_backward_vs_oracle(mode, tol, gtol):
+    cfg = _cfg()
+    sd = O.fill_state(cfg, 11)
+    batch = O.synthetic_batch([2, 1], 5, cfg)
+    n_img = int(batch[7].sum())
+    d_out = torch.randn(n_img, 64, generator=torch.Generator().manual_seed(3))
+    ref, taps, g_ref = _oracle(cfg, sd, batch, d_out)
+    assert ref.shape == (n_img, 64)                                   # shape fact: [N,3,400,280] -> [N,out]
+    assert tuple(taps[PFX + ":mid"].shape[2:]) == (1, 1)                # ... through a 1x1 final map
+    eng, data, grads = _engine(cfg, sd, mode, True)
+    out = torch.empty(n_img, 64, device="cuda")
+    eng.forward(batch[5].cuda(), batch[6].cuda(), n_img, out, train=True, seed=1)
+    errs = {}
+    for tap in ("conv_in", "block0", "block1", "block4", "block8", "mid"):
+        mine = eng.tap(tap).permute(0, 3, 1, 2).float().cpu()
+        errs[tap] = ((mine.double() - taps[f"{PFX}:{tap}"]).norm() / taps[f"{PFX}:{tap}"].norm()).item()
+    errs["out"] = ((out.cpu().double() - ref).norm() / ref.norm()).item()
+    print("sdxl forward rel L2 errors, mode", mode, errs)
+    assert max(errs.values()) < tol, errs
+    eng.backward(d_out.cuda())
+    torch.cuda.synchronize()
+    worst, bad = 0.0, []
+    for k, r in g_ref.items():
+        mine = grads[k].cpu().double().reshape(r.shape)
+        if "to_q" in k or "to_k" in k:                                 # one token: softmax == 1, no gradient
+            assert mine.abs().max().item() == 0.0 and r.abs().max().item() < 1e-12
+            continue
+        e = ((mine - r).norm() / r.norm().clamp_min(1e-30)).item()
+        worst = max(worst, e)
+        if e > gtol:
+            bad.append((k, e))
+    print("sdxl backward worst rel L2 gradient error, mode", mode, worst, bad[:6])
+    assert not bad, bad[:8]
+
+
+def test_sdxl_full_model_train_step_vs_oracle():
+    cfg = _cfg()
+    sd = O.fill_state(cfg, 7)
+    batch = O.synthetic_batch([2, 3, 1], 9, cfg)
+    (total, el, pl), (ev, pr), grads, _ = O.train_step(sd, cfg, batch)
+    model = build_trainer(cfg, sd)
+    assert type(model).__name__ == "NeutrinoFullSDXLTrainer"
+    model.train()
+    model.network.hip_runtime().zero_grad()
+    loss = model.training_step(to_device(batch), 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - total.item()) < 2e-4 * abs(total.item()), (loss.item(), total.item())
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for k, r in grads.items():
+        if r.abs().max() < 1e-7:
+            continue
+        e = ((named[k].grad.cpu() - r).norm() / r.norm()).item()
+        worst = max(worst, e)
+        assert e < 5e-3, (k, e)
+    print("sdxl full model: loss", loss.item(), total.item(), "worst rel L2 gradient error", worst)
+    model.eval()
+    with torch.no_grad():
+        _, _, ev_g, pr_g = model.shared_step(to_device(batch))
+    _, _, ev_o, pr_o, _ = O.shared_step(sd, cfg, batch, training=False)
+    assert rel_err(ev_g.cpu(), ev_o) < 1e-3 and rel_err(pr_g.cpu(), pr_o) < 1e-3
