@@ -77,6 +77,26 @@ def cpu_model():
     return "unknown"
 
 
+def sdxl_flops_per_image(init_ch=64, out_dim=256, H=400, W=280, in_ch=3):
+    """conv MACs x2 of one SDXL-embedder pass (layers/sdxl_net.py:19-34 schedule), forward and forward+backward (3x forward minus
+    the data gradient of conv_in, which has no input gradient)."""
+    chans = [init_ch, init_ch, 2 * init_ch, 2 * init_ch, 4 * init_ch, 4 * init_ch, 8 * init_ch, 8 * init_ch, out_dim]
+    fwd = 2.0 * H * W * 9 * in_ch * chans[0]
+    conv_in = fwd
+    cin, h, w = chans[0], H, W
+    for i, c in enumerate(chans):
+        fwd += 2.0 * h * w * 9 * (cin * c + c * c) + 2.0 * h * w * 9 * 2 * c * c            # resnet 0 + resnet 1
+        if cin != c:
+            fwd += 2.0 * h * w * cin * c
+        if i + 1 != len(chans):
+            h, w = (h - 2) // 2 + 1, (w - 2) // 2 + 1
+            fwd += 2.0 * h * w * 9 * c * c
+        cin = c
+    c = chans[-1]
+    fwd += 2.0 * h * w * (4 * 9 * c * c + 2 * c * c) + 2.0 * h * w * 9 * c * out_dim + 2.0 * out_dim * out_dim
+    return fwd, 3.0 * fwd - conv_in
+
+
 def make_batch(batch, prongs, seed, device):
     from transformercvn.dataset.minkowski_dataset import SyntheticDataset, MinkowskiCollection
     ds = SyntheticDataset(batch, prongs, seed=seed)
@@ -159,7 +179,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--sdxl", action="store_true", help="BASELINE config 4: the SDXL-style embedder (train.py --sdxl), batch 16")
+    ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--prongs", type=int, default=8)
     ap.add_argument("--dropout", type=float, default=None, help="override options.dropout (experiments only; the metric uses the file's 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,6 +188,8 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing (fp32_ms_per_step)")
     ap.add_argument("--dump-records", default="", help="write every profiled launch (name, ms, flops) to this JSON file")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 16 if args.sdxl else 32
 
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -186,6 +209,8 @@ def main():
 
     from transformercvn.options import Options
     from transformercvn.network.trainers.neutrino_full_dense_trainer import NeutrinoFullDenseTrainer
+    if args.sdxl:
+        from transformercvn.network.trainers.neutrino_full_sdxl_trainer import NeutrinoFullSDXLTrainer as NeutrinoFullDenseTrainer
     from transformercvn.hip import _lib
     from transformercvn.hip.distributed import GradReducer, broadcast_buffers
 
@@ -311,14 +336,20 @@ def main():
     if rank == 0:
         events = world * args.batch * args.steps
         value = events / elapsed
-        per_gpu_tflops = (args.batch * (1 + args.prongs) * FLOP_PER_IMAGE_FWD_BWD) / (elapsed / args.steps) / 1e12
+        flop_img = FLOP_PER_IMAGE_FWD_BWD
+        if args.sdxl:        # per-image FLOPs of the two embedders differ only in the last stage (out 256 / 288): use the prong value
+            flop_img = (args.prongs * sdxl_flops_per_image(out_dim=256)[1] + sdxl_flops_per_image(out_dim=288)[1]) / (1 + args.prongs)
+        per_gpu_tflops = (args.batch * (1 + args.prongs) * flop_img) / (elapsed / args.steps) / 1e12
         out = {
-            "metric": "events/sec (fwd+bwd) at batch=32, 8 prongs/event; fraction of MFMA roofline",
+            "metric": "events/sec (fwd+bwd) at batch=32, 8 prongs/event; fraction of MFMA roofline" if not args.sdxl else
+                      "events/sec (fwd+bwd) at batch=16, 8 prongs/event, --sdxl embedder; fraction of MFMA roofline",
             "value": round(value, 2), "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"TransformerCVN DenseNet [3,6,12,6,3] g32, fwd+loss+bwd, batch {args.batch}/GPU, "
-                                   f"{args.prongs} prongs/event, 3x400x280 maps, 6-layer encoder, dropout 0.1",
+            "config": {"workload": (f"TransformerCVN DenseNet [3,6,12,6,3] g32, fwd+loss+bwd, batch {args.batch}/GPU, "
+                                    f"{args.prongs} prongs/event, 3x400x280 maps, 6-layer encoder, dropout 0.1") if not args.sdxl else
+                                   (f"TransformerCVN --sdxl embedder (VAE-encoder blocks [64,64,128,128,256,256,512,512,out], GroupNorm(1), "
+                                    f"parity unpinned), fwd+loss+bwd, batch {args.batch}/GPU, {args.prongs} prongs/event, 3x400x280 maps"),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "precision": args.precision},
             "model_tflops_per_gpu": round(per_gpu_tflops, 2),
             "frac_of_mfma_peak_whole_step": round(per_gpu_tflops / PEAK[args.precision], 4),
@@ -327,13 +358,13 @@ def main():
         if roof:
             out["roofline"] = roof
             out["kernels"] = kernels[:8]
-        if args.precision == "bf16" and world == 1 and not args.no_fp32:
+        if args.precision == "bf16" and world == 1 and not args.no_fp32 and not args.sdxl:
             note("fp32 parity mode (1 warm-up + 2 steps) ...")
             del model, rt
             torch.cuda.empty_cache()
             out["fp32_ms_per_step"] = round(fp32_parity_mode_ms(opt_path, args, dev, batch), 2)
             out["fp32_events_per_s"] = round(args.batch / out["fp32_ms_per_step"] * 1000, 1)
-        if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only
+        if not args.no_cpu_baseline and world == 1 and not args.sdxl:       # rank 0 at N=1 only (DenseNet workload)
             note("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline(host_threads(), args.prongs)
         print(json.dumps(out))

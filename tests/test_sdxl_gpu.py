@@ -45,7 +45,7 @@ def _oracle(cfg, sd, batch, d_out=None, dtype=torch.float64):
     return out.detach(), {k: v.detach() for k, v in taps.items()}, grads
 
 
-@pytest.mark.parametrize("mode,tol,gtol", [(0, 2e-4, 2e-3), (1, 5e-2, 1.5e-1)])
+@pytest.mark.parametrize("mode,tol,gtol", [(0, 2e-5, 1e-4), (1, 3e-2, 8e-2)])      # measured: 1.1e-6 / 7.6e-6 and 1.3e-2 / 3.9e-2
 def test_sdxl_embedder_forward_backward_vs_oracle(mode, tol, gtol):
     cfg = _cfg()
     sd = O.fill_state(cfg, 11)
@@ -98,6 +98,9 @@ def test_sdxl_full_model_train_step_vs_oracle():
     worst = 0.0
     for k, r in grads.items():
         if r.abs().max() < 1e-7:
+            continue
+        if k.endswith("event_position_embedding"):       # true gradient exactly 0 (a train-mode BatchNorm1d follows): rounding noise
+            assert named[k].grad.abs().max().item() < 1e-4
             continue
         e = ((named[k].grad.cpu() - r).norm() / r.norm()).item()
         worst = max(worst, e)
