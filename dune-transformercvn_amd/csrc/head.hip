@@ -155,6 +155,20 @@ int HeadPlan::encode(int B, int P, const int32_t* tok_row, char* ws, const HLayo
     const float dp = train ? cfg.dropout : 0.f;
     auto F = [&](long off) { return reinterpret_cast<float*>(ws + off); };
     int rc;
+    if (fused_encoder && encoder_fused_ok(S, D, H, cfg.n_layers, cfg.norm_first)) {      // one launch for the whole stack (+ mask)
+        EncFusedArgs a{};
+        a.X0 = F(L.X[0]); a.tok_row = tok_row; a.HID = F(L.HID); a.B = B; a.S = S; a.H = H; a.L = cfg.n_layers; a.gelu = cfg.gelu;
+        a.save = 1; a.eps = kEps; a.drop_p = dp; a.seed = seed;
+        for (int l = 0; l < cfg.n_layers; ++l) {
+            const HLayer& W = layers[l];
+            const HLayBuf& q = L.lay[l];
+            a.w[l] = EncLayerW{data[W.win], data[W.bin], data[W.wo], data[W.bo], data[W.w1], data[W.b1], data[W.w2], data[W.b2],
+                               data[W.g1], data[W.be1], data[W.g2], data[W.be2]};
+            a.buf[l] = EncLayerBuf{F(q.qkv), F(q.probs), F(q.ctx), F(q.xh1), F(q.rstd1), F(q.x1), F(q.hpre), F(q.hact), F(q.xh2),
+                                   F(q.rstd2), F(L.X[l + 1])};
+        }
+        return encoder_fused_fwd(a, st);
+    }
     for (int l = 0; l < cfg.n_layers; ++l) {
         const HLayer& W = layers[l];
         const HLayBuf& q = L.lay[l];
@@ -333,6 +347,7 @@ int tcvn_head_slot(const tcvn_head* p, int i, char* name, int cap, int64_t* nume
     return 0;
 }
 int tcvn_head_bind(tcvn_head* p, void* const* data, void* const* grad) { return p->plan.bind(data, grad); }
+void tcvn_head_set_fused_encoder(tcvn_head* p, int on) { p->plan.fused_encoder = on != 0; }
 int64_t tcvn_head_workspace_bytes(const tcvn_head* p, int batch, int max_prongs, int n_prongs) {
     HLayout L;
     p->plan.layout(batch, max_prongs, n_prongs, L);

@@ -28,6 +28,7 @@ struct HeadPlan {
     std::vector<HLayer> layers;
     std::vector<HDec> dec;
     bool bound = false;
+    bool fused_encoder = true;     // encoder_fused.hip when the shape allows (tcvn_head_set_fused_encoder(p, 0): unfused kernels, for A/B tests)
     uint64_t last_seed = 0; int last_train = 0;
 
     explicit HeadPlan(const tcvn_head_cfg& c);

@@ -36,6 +36,18 @@ int act_fwd(const float* X, float* Y, long n, int gelu, float drop_p, uint64_t s
 int act_bwd(const float* X, const float* dY, float* dX, long n, int gelu, float drop_p, uint64_t seed, uint32_t sid, hipStream_t st);
 int add_inplace(float* dst, const float* src, long n, hipStream_t st);
 
+// Fused encoder forward (encoder_fused.hip): all layers in one launch, one workgroup per event.  Weight / buffer pointers per layer.
+constexpr int ENC_MAX_LAYERS = 8;
+struct EncLayerW { const float *win, *bin, *wo, *bo, *w1, *b1, *w2, *b2, *g1, *be1, *g2, *be2; };
+struct EncLayerBuf { float *qkv, *probs, *ctx, *xh1, *rstd1, *x1, *hpre, *hact, *xh2, *rstd2, *xnext; };
+struct EncFusedArgs {
+    const float* X0; const int* tok_row; float* HID;
+    int B, S, H, L, gelu, save; float eps, drop_p; uint64_t seed;
+    EncLayerW w[ENC_MAX_LAYERS]; EncLayerBuf buf[ENC_MAX_LAYERS];
+};
+bool encoder_fused_ok(int S, int D, int H, int L, int norm_first);
+int encoder_fused_fwd(const EncFusedArgs& a, hipStream_t st);
+
 int focal_i64(const float* logits, const int64_t* targets, int rows, int C, float gamma, float weight, float* dlogits, float* out,
               hipStream_t st);
 int focal_i8(const float* logits, const int8_t* targets, int rows, int C, float gamma, float weight, float* dlogits, float* out,

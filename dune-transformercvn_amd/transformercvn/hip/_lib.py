@@ -81,6 +81,7 @@ def _load():
     sig("tcvn_head_forward", i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, i64, i32, u64, vp)
     sig("tcvn_head_loss", i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp)
     sig("tcvn_head_backward", i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp)
+    sig("tcvn_head_set_fused_encoder", None, vp, i32)
     sig("tcvn_head_embed", i32, vp, i32, i32, i32, vp, vp, vp, vp, i64, i32, u64, vp)
     sig("tcvn_head_encode", i32, vp, i32, i32, vp, vp, vp, vp, i64, i32, u64, vp)
     sig("tcvn_head_decode", i32, vp, i32, i32, vp, vp, vp, vp, i64, i32, u64, vp)
@@ -112,7 +113,7 @@ def profile_records():
 
 EXPORTS = [
     "tcvn_grad_sumsq", "tcvn_adamw_step", "tcvn_backward_overlap", "tcvn_profile_enable", "tcvn_profile_filter", "tcvn_profile_reset", "tcvn_profile_count", "tcvn_profile_get",
-    "tcvn_focal_loss", "tcvn_dropout_keep", "tcvn_head_embed", "tcvn_head_encode", "tcvn_head_decode", "tcvn_linear_forward",
+    "tcvn_focal_loss", "tcvn_dropout_keep", "tcvn_head_set_fused_encoder", "tcvn_head_embed", "tcvn_head_encode", "tcvn_head_decode", "tcvn_linear_forward",
     "tcvn_rows_bn_prelu_forward", "tcvn_sdxl_create", "tcvn_sdxl_destroy", "tcvn_sdxl_num_slots", "tcvn_sdxl_slot", "tcvn_sdxl_bind",
     "tcvn_sdxl_workspace_bytes", "tcvn_sdxl_forward", "tcvn_sdxl_backward", "tcvn_sdxl_tap",
     "tcvn_version", "tcvn_densenet_create", "tcvn_densenet_destroy", "tcvn_densenet_num_slots", "tcvn_densenet_slot",

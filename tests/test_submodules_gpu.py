@@ -76,3 +76,39 @@ def test_stage_calls_on_cpu_fail_loudly():
     model = build_trainer(cfg, None, device=None)
     with pytest.raises(RuntimeError):
         model.network.event_decoder(torch.zeros(2, cfg.hidden_dim))
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_fused_encoder_matches_layer_by_layer_kernels(training):
+    """csrc/encoder_fused.hip (one launch, one workgroup per event) against the row kernels it replaces, same inputs, incl.
+    dropout (same stateless masks) and a ragged key-padding mask: hidden states to fp32 summation-order level, and the saved
+    tensors the backward reads (it runs on the unfused kernels either way) give the same parameter gradients."""
+    from transformercvn.hip._lib import lib
+    cfg, over, batch, g = load_case("tutorial_ragged")               # prongs 1 / 16 / 5: S = 17 with padding
+    sd = O.fill_state(cfg, int(g["weight_seed"]))
+    res = {}
+    for fused in (1, 0):
+        model = build_trainer(cfg, sd)
+        model.train(training)
+        rt = model.network.hip_runtime()
+        rt.ensure_bound()
+        lib.tcvn_head_set_fused_encoder(rt.head.handle, fused)
+        rt.zero_grad()
+        if training:
+            loss = model.training_step(to_device(batch), 0)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[fused] = (loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if "encoder" in k or "decoder" in k})
+        else:
+            with torch.no_grad():
+                _, _, ev, pr = model.shared_step(to_device(batch))
+            res[fused] = (ev.clone(), pr.clone())
+    if training:
+        assert abs(res[1][0] - res[0][0]) < 2e-6 * abs(res[0][0]), (res[1][0], res[0][0])
+        worst = max(((res[1][1][k] - res[0][1][k]).norm() / res[0][1][k].norm().clamp_min(1e-30)).item() for k in res[0][1])
+        print("fused vs unfused encoder, train (dropout 0.1): loss", res[1][0], res[0][0], "worst grad rel L2", worst)
+        assert worst < 2e-4
+    else:
+        e = max(rel_err(res[1][0].cpu(), res[0][0].cpu()), rel_err(res[1][1].cpu(), res[0][1].cpu()))
+        print("fused vs unfused encoder, eval: logit rel err", e)
+        assert e < 1e-5
