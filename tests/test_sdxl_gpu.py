@@ -106,6 +106,7 @@ def test_sdxl_full_model_train_step_vs_oracle():
         worst = max(worst, e)
         assert e < 5e-3, (k, e)
     print("sdxl full model: loss", loss.item(), total.item(), "worst rel L2 gradient error", worst)
+    model = build_trainer(cfg, sd)                 # fresh module: the train step above moved the BatchNorm running statistics
     model.eval()
     with torch.no_grad():
         _, _, ev_g, pr_g = model.shared_step(to_device(batch))

@@ -98,14 +98,17 @@ def test_fused_encoder_matches_layer_by_layer_kernels(training):
             loss = model.training_step(to_device(batch), 0)
             loss.backward()
             torch.cuda.synchronize()
-            res[fused] = (loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if "encoder" in k or "decoder" in k})
+            res[fused] = (loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if "network.encoder." in k})
         else:
             with torch.no_grad():
                 _, _, ev, pr = model.shared_step(to_device(batch))
             res[fused] = (ev.clone(), pr.clone())
     if training:
         assert abs(res[1][0] - res[0][0]) < 2e-6 * abs(res[0][0]), (res[1][0], res[0][0])
-        worst = max(((res[1][1][k] - res[0][1][k]).norm() / res[0][1][k].norm().clamp_min(1e-30)).item() for k in res[0][1])
+        scale = max(v.norm().item() for v in res[0][1].values())
+        errs = sorted((((res[1][1][k] - res[0][1][k]).norm() / (res[0][1][k].norm() + 1e-4 * scale)).item(), k) for k in res[0][1])
+        print("largest differences:", errs[-3:])
+        worst = errs[-1][0]
         print("fused vs unfused encoder, train (dropout 0.1): loss", res[1][0], res[0][0], "worst grad rel L2", worst)
         assert worst < 2e-4
     else:
