@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void k_encoder_fwd(const EncFusedArgs a) {
 }  // namespace
 
 bool encoder_fused_ok(int S, int Dm, int H, int L, int norm_first) {
-    return Dm == D && (H == 4 || H == 8 || H == 16) && S >= 1 && S <= SMAX && L >= 1 && L <= ENC_MAX_LAYERS && !norm_first;
+    return Dm == D && (H == 4 || H == 8) && S >= 1 && S <= SMAX && L >= 1 && L <= ENC_MAX_LAYERS && !norm_first;
 }
 
 int encoder_fused_fwd(const EncFusedArgs& a, hipStream_t st) {
@@ -247,6 +247,328 @@ int encoder_fused_fwd(const EncFusedArgs& a, hipStream_t st) {
     if (a.H == 4) hipLaunchKernelGGL(k_encoder_fwd<32>, dim3(a.B), dim3(256), smem, st, a);
     else if (a.H == 8) hipLaunchKernelGGL(k_encoder_fwd<16>, dim3(a.B), dim3(256), smem, st, a);
     else hipLaunchKernelGGL(k_encoder_fwd<8>, dim3(a.B), dim3(256), smem, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace tcvn
+
+// =====================================================================================================================
+// Fused encoder BACKWARD: one launch for the data-gradient chain of all layers (one workgroup per event, gradients of an
+// event's tokens in LDS), one launch for every weight / bias / LayerNorm gradient (k_encoder_wgrad: a grouped TN GEMM over the
+// T = S*B token rows, single writer per element -> deterministic, no atomics).  The chain kernel leaves the per-layer GEMM
+// operands (d qkv, d attention-out, d FFN pre-activation, d FFN out) and per-event LayerNorm partial sums in the workspace.
+// Reads exactly what either forward saved.  Autograd of torch.nn.TransformerEncoderLayer (post-norm), same call sites as above.
+// =====================================================================================================================
+namespace tcvn {
+namespace {
+
+constexpr int HR = 64;          // rows of a weight half-block staged at a time (dX = dY W contracts over W's rows)
+
+__device__ __forceinline__ void wh_issue(const float* __restrict__ W, float4 (&reg)[8]) {       // 64 rows x 128 floats
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        reg[i] = *reinterpret_cast<const float4*>(W + (idx >> 5) * D + (idx & 31) * 4);
+    }
+}
+__device__ __forceinline__ void wh_commit(float* Wl, const float4 (&reg)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        *reinterpret_cast<float4*>(Wl + (idx >> 5) * WLD + (idx & 31) * 4) = reg[i];
+    }
+}
+// acc[i] += sum_{n < 64} dy[g + 2 i][n0 + n] * Wl[n][k]
+__device__ __forceinline__ void gemm_t64(const float* dy, int ldy, int n0, int nrows, int g, const float* Wl, int k, float (&acc)[RMAX]) {
+    for (int n = 0; n < HR; n += 4) {
+        const float w0 = Wl[(n + 0) * WLD + k], w1 = Wl[(n + 1) * WLD + k], w2 = Wl[(n + 2) * WLD + k], w3 = Wl[(n + 3) * WLD + k];
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i)
+            if (i < nrows) {
+                const float4 y = *reinterpret_cast<const float4*>(dy + (g + 2 * i) * ldy + n0 + n);
+                acc[i] = fmaf(y.x, w0, acc[i]); acc[i] = fmaf(y.y, w1, acc[i]);
+                acc[i] = fmaf(y.z, w2, acc[i]); acc[i] = fmaf(y.w, w3, acc[i]);
+            }
+    }
+}
+
+// LayerNorm backward of the rows in `dy` (LDS): ds -> `res` (LDS, the residual branch) and drop * ds -> `br` (LDS) + `brg` (global).
+// Per-event column sums of dy*xhat and dy go to lnp[0][c], lnp[1][c] (global, this event's slice) via `red` (LDS, 4 x 256 floats).
+__device__ __forceinline__ void ln_bwd_rows(const float* dy, int S, int B, int b, const float* gamma, const float* xhg, const float* rstdg,
+                                            float* res, float* br, float* brg, float dp, uint64_t seed, uint32_t sid, float* red, float* lnp) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float ga0 = 0.f, ga1 = 0.f, be0 = 0.f, be1 = 0.f;
+    const float g0 = gamma[lane], g1 = gamma[lane + 64];
+    for (int s = wave; s < S; s += 4) {
+        const long t = (long)s * B + b;
+        const float y0 = dy[s * D + lane], y1 = dy[s * D + lane + 64];
+        const float h0 = xhg[t * D + lane], h1 = xhg[t * D + lane + 64];
+        ga0 = fmaf(y0, h0, ga0); ga1 = fmaf(y1, h1, ga1); be0 += y0; be1 += y1;
+        const float a0 = y0 * g0, a1 = y1 * g1;
+        const float s1 = wave_sum(a0 + a1) / D, s2 = wave_sum(a0 * h0 + a1 * h1) / D;
+        const float rstd = rstdg[t];
+        const float d0 = rstd * (a0 - s1 - h0 * s2), d1 = rstd * (a1 - s1 - h1 * s2);
+        res[s * D + lane] = d0; res[s * D + lane + 64] = d1;
+        float r0 = d0, r1 = d1;
+        if (dp > 0.f) { r0 *= drop_scale(dp, seed, sid, (uint64_t)t * D + lane); r1 *= drop_scale(dp, seed, sid, (uint64_t)t * D + lane + 64); }
+        br[s * D + lane] = r0; br[s * D + lane + 64] = r1;
+        brg[t * D + lane] = r0; brg[t * D + lane + 64] = r1;
+    }
+    red[wave * 256 + lane] = ga0; red[wave * 256 + 64 + lane] = ga1; red[wave * 256 + 128 + lane] = be0; red[wave * 256 + 192 + lane] = be1;
+    __syncthreads();
+    {
+        const int i = threadIdx.x;                       // 0..127: dgamma column, 128..255: dbeta column
+        const float v = red[i] + red[256 + i] + red[512 + i] + red[768 + i];
+        lnp[i] = v;
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 1) void k_encoder_bwd(const EncFusedBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int S = a.S, B = a.B, b = blockIdx.x, tid = threadIdx.x;
+    float* Wl = lds;                         // [64][WLD]; doubles as the dS / Pd exchange and the LayerNorm reduction scratch
+    float* bA = Wl + HR * WLD;               // [S][D]
+    float* bB = bA + S * D;                  // [S][D]
+    float* bC = bB + S * D;                  // [S][D]
+    float* bQ = bC + S * D;                  // [S][QLD] saved q | k | v
+    float* bDQ = bQ + S * QLD;               // [S][QLD] d(q | k | v)
+    const int k = tid & 127, g = tid >> 7;
+    const int nrows = (S - g + 1) / 2;
+    constexpr int hd = HD;
+    const int H = D / HD;
+    const float dp = a.drop_p;
+    for (int i = tid; i < S * D; i += 256) {
+        const int s = i / D, d = i - s * D;
+        bA[i] = a.dY[((long)s * B + b) * D + d];
+    }
+    float4 wreg[8];
+    float acc[RMAX];
+    wh_issue(a.w[a.L - 1].w2, wreg);
+    __syncthreads();
+    for (int l = a.L - 1; l >= 0; --l) {
+        const EncLayerW& W = a.w[l];
+        const EncLayerBuf& O = a.buf[l];
+        const EncLayerGrad& G = a.g[l];
+        const uint32_t sid = 0x6000u + l * 8;
+        float* lnp = a.lnp + ((long)b * a.L + l) * 4 * D;
+        // ---- LayerNorm 2 backward: bA = d x_{l+1} -> bB = d x1 (residual), bC = d f (dropped) -----------------------------------
+        ln_bwd_rows(bA, S, B, b, W.g2, O.xh2, O.rstd2, bB, bC, G.df, dp, a.seed, sid + 3, Wl, lnp + 2 * D);
+        // ---- d hact = d f W2 ; d hpre = d hact * drop * act'(hpre) -> bA -------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i) acc[i] = 0.f;
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {
+            __syncthreads();
+            wh_commit(Wl, wreg);
+            __syncthreads();
+            wh_issue(hf == 0 ? W.w2 + HR * D : W.w1, wreg);
+            gemm_t64(bC, D, hf * HR, nrows, g, Wl, k, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i)
+            if (i < nrows) {
+                const int s = g + 2 * i;
+                const long t = (long)s * B + b;
+                const float x = O.hpre[t * D + k];
+                float gr = acc[i];
+                if (dp > 0.f) gr *= drop_scale(dp, a.seed, sid + 2, (uint64_t)t * D + k);
+                const float dact = a.gelu ? 0.5f * (1.f + erff(x * kInvSqrt2)) + x * 0.3989422804014327f * expf(-0.5f * x * x) : (x > 0.f ? 1.f : 0.f);
+                const float v = gr * dact;
+                bA[s * D + k] = v;
+                G.dhp[t * D + k] = v;
+            }
+        // ---- d x1 += d hpre W1 -------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i) acc[i] = 0.f;
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {
+            __syncthreads();
+            wh_commit(Wl, wreg);
+            __syncthreads();
+            wh_issue(hf == 0 ? W.w1 + HR * D : W.wo, wreg);
+            gemm_t64(bA, D, hf * HR, nrows, g, Wl, k, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i)
+            if (i < nrows) bB[(g + 2 * i) * D + k] += acc[i];
+        __syncthreads();
+        // ---- LayerNorm 1 backward: bB = d x1 -> bA = d x_l (residual), bC = d attention-out (dropped) ---------------------------
+        ln_bwd_rows(bB, S, B, b, W.g1, O.xh1, O.rstd1, bA, bC, G.dao, dp, a.seed, sid + 1, Wl, lnp);
+        // ---- d ctx = d ao Wo -> bB ; meanwhile the saved q | k | v come in ---------------------------------------------------
+        for (int i = tid; i < S * 3 * D; i += 256) {
+            const int s = i / (3 * D), d = i - s * 3 * D;
+            bQ[s * QLD + d] = O.qkv[((long)s * B + b) * 3 * D + d];
+        }
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i) acc[i] = 0.f;
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {
+            __syncthreads();
+            wh_commit(Wl, wreg);
+            __syncthreads();
+            wh_issue(hf == 0 ? W.wo + HR * D : W.win, wreg);
+            gemm_t64(bC, D, hf * HR, nrows, g, Wl, k, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i)
+            if (i < nrows) bB[(g + 2 * i) * D + k] = acc[i];
+        __syncthreads();
+        // ---- attention backward: thread (h, s); dS and the dropped probabilities are exchanged through the W image ---------------
+        float* xS = Wl;                                   // [H][S][SMAX + 1]
+        float* xP = Wl + H * S * (SMAX + 1);              // [H][S][SMAX + 1]   (2 * 8 * 22 * 23 floats <= 64 * 132)
+        if (tid < H * S) {
+            const int s = tid % S, h = tid / S;
+            const float* P = O.probs + (((long)b * H + h) * S + s) * S;
+            float dc[HD];
+#pragma unroll
+            for (int e = 0; e < HD; ++e) dc[e] = bB[s * D + h * hd + e];
+            float dpj[SMAX], pj[SMAX];
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < SMAX; ++j) {
+                dpj[j] = 0.f; pj[j] = 0.f;
+                if (j < S) {
+                    const float* v = bQ + j * QLD + 2 * D + h * hd;
+                    float gsum = 0.f;
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) gsum = fmaf(dc[e], v[e], gsum);
+                    float m = 1.f;
+                    if (dp > 0.f) m = drop_scale(dp, a.seed, sid, (((uint64_t)b * H + h) * S + s) * S + j);
+                    pj[j] = P[j];
+                    xP[(h * S + s) * (SMAX + 1) + j] = pj[j] * m;
+                    dpj[j] = gsum * m;
+                    dot = fmaf(dpj[j], pj[j], dot);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SMAX; ++j)
+                if (j < S) xS[(h * S + s) * (SMAX + 1) + j] = pj[j] * (dpj[j] - dot);
+        }
+        __syncthreads();
+        if (tid < H * S) {
+            const int s = tid % S, h = tid / S;
+            const float scale = rsqrtf((float)hd);
+            float dq[HD], dk[HD], dv[HD];
+#pragma unroll
+            for (int e = 0; e < HD; ++e) { dq[e] = 0.f; dk[e] = 0.f; dv[e] = 0.f; }
+            for (int j = 0; j < S; ++j) {
+                const float dsj = xS[(h * S + s) * (SMAX + 1) + j], dst = xS[(h * S + j) * (SMAX + 1) + s], pdt = xP[(h * S + j) * (SMAX + 1) + s];
+                const float* kj = bQ + j * QLD + D + h * hd;
+                const float* qj = bQ + j * QLD + h * hd;
+                const float* dcj = bB + j * D + h * hd;
+#pragma unroll
+                for (int e = 0; e < HD; ++e) {
+                    dq[e] = fmaf(dsj, kj[e], dq[e]);
+                    dk[e] = fmaf(dst, qj[e], dk[e]);
+                    dv[e] = fmaf(pdt, dcj[e], dv[e]);
+                }
+            }
+            float* og = G.dqkv + ((long)s * B + b) * 3 * D + h * hd;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) {
+                const float q = dq[e] * scale, kk = dk[e] * scale;
+                bDQ[s * QLD + h * hd + e] = q; bDQ[s * QLD + D + h * hd + e] = kk; bDQ[s * QLD + 2 * D + h * hd + e] = dv[e];
+                og[e] = q; og[D + e] = kk; og[2 * D + e] = dv[e];
+            }
+        }
+        // ---- d x_l = bA + d qkv Win (six half blocks) ------------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i) acc[i] = 0.f;
+#pragma unroll 1
+        for (int hf = 0; hf < 6; ++hf) {
+            __syncthreads();
+            wh_commit(Wl, wreg);
+            __syncthreads();
+            if (hf < 5) wh_issue(W.win + (hf + 1) * HR * D, wreg);
+            else if (l > 0) wh_issue(a.w[l - 1].w2, wreg);
+            gemm_t64(bDQ, QLD, hf * HR, nrows, g, Wl, k, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i)
+            if (i < nrows) bA[(g + 2 * i) * D + k] += acc[i];
+        __syncthreads();
+    }
+    for (int i = tid; i < S * D; i += 256) {
+        const int s = i / D, d = i - s * D;
+        a.dX[((long)s * B + b) * D + d] = bA[i];
+    }
+}
+
+// ---- grouped weight gradients: dW[n][k] += sum_t dY[t][n] X[t][k], db[n] += sum_t dY[t][n]; LayerNorm parameter sums ----------------
+__global__ __launch_bounds__(256) void k_encoder_wgrad(const EncWgradArgs a) {
+    __shared__ float Xs[32][D];
+    __shared__ float Ys[32][2][16];
+    const int tid = threadIdx.x;
+    int blk = blockIdx.x;
+    if (blk >= a.n_tiles) {                                        // LayerNorm parameter gradients: sum the per-event partials
+        const int idx = (blk - a.n_tiles) * 256 + tid;              // (layer, which of 4, column)
+        if (idx < a.L * 4 * D) {
+            const int l = idx / (4 * D), r = idx - l * 4 * D;
+            float s = 0.f;
+            for (int b = 0; b < a.B; ++b) s += a.lnp[((long)b * a.L + l) * 4 * D + r];
+            a.ln_dst[l][r / D][r % D] += s;
+        }
+        return;
+    }
+    int j = 0;
+    while (blk >= a.job[j].tiles) { blk -= a.job[j].tiles; ++j; }
+    const EncWgradJob J = a.job[j];
+    const int n0 = blk * 32;
+    const int k = tid & 127, g = tid >> 7;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float bsum = 0.f;
+    for (int t0 = 0; t0 < a.T; t0 += 32) {
+        __syncthreads();
+        for (int i = tid; i < 32 * D; i += 256) {
+            const int t = i / D, c = i - t * D;
+            Xs[t][c] = t0 + t < a.T ? J.X[(long)(t0 + t) * D + c] : 0.f;
+        }
+        for (int i = tid; i < 32 * 32; i += 256) {
+            const int t = i >> 5, n = i & 31;
+            Ys[t][n & 1][n >> 1] = t0 + t < a.T ? J.dY[(long)(t0 + t) * J.ldy + n0 + n] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int t = 0; t < 32; ++t) {
+            const float x = Xs[t][k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 y = *reinterpret_cast<const float4*>(&Ys[t][g][q * 4]);
+                acc[q * 4 + 0] = fmaf(y.x, x, acc[q * 4 + 0]); acc[q * 4 + 1] = fmaf(y.y, x, acc[q * 4 + 1]);
+                acc[q * 4 + 2] = fmaf(y.z, x, acc[q * 4 + 2]); acc[q * 4 + 3] = fmaf(y.w, x, acc[q * 4 + 3]);
+            }
+        }
+        if (tid < 32)
+            for (int t = 0; t < 32; ++t) bsum += Ys[t][tid & 1][tid >> 1];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) J.dW[(long)(n0 + g + 2 * i) * D + k] += acc[i];
+    if (tid < 32) J.db[n0 + tid] += bsum;
+}
+
+}  // namespace
+
+int encoder_fused_bwd(const EncFusedBwdArgs& a, const EncWgradArgs& w, hipStream_t st) {
+    if (!encoder_fused_ok(a.S, D, a.H, a.L, 0)) return -2;
+    const size_t smem = ((size_t)HR * WLD + (size_t)a.S * (3 * D + 2 * QLD)) * 4 + 64;
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_bwd<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_bwd<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    if (smem > 160 * 1024 || 2 * a.H * a.S * (SMAX + 1) > HR * WLD) return -2;
+    if (a.H == 4) hipLaunchKernelGGL(k_encoder_bwd<32>, dim3(a.B), dim3(256), smem, st, a);
+    else if (a.H == 8) hipLaunchKernelGGL(k_encoder_bwd<16>, dim3(a.B), dim3(256), smem, st, a);
+    else hipLaunchKernelGGL(k_encoder_bwd<8>, dim3(a.B), dim3(256), smem, st, a);
+    TCVN_LAUNCH_CHECK();
+    const int ln_blocks = cdiv((long)a.L * 4 * D, 256);
+    hipLaunchKernelGGL(k_encoder_wgrad, dim3(w.n_tiles + ln_blocks), dim3(256), 0, st, w);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

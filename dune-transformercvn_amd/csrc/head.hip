@@ -129,6 +129,12 @@ void HeadPlan::layout(int B, int P, int nP, HLayout& L) const {
     L.dLG = b.take((long)TP * cfg.prong_classes * 4);
     L.t0 = b.take(3 * td); L.t1 = b.take(3 * td); L.t2 = b.take(td); L.t3 = b.take(td); L.dHID = b.take(td);
     L.dC = b.take((long)R * D * 4); L.dZc = b.take((long)R * D * 4);
+    // fused encoder backward: per-layer weight-gradient operands and per-event LayerNorm sums
+    for (int l = 0; l < cfg.n_layers; ++l) {
+        HLayBuf& q = L.lay[l];
+        q.g_dqkv = b.take(3 * td); q.g_dao = b.take(td); q.g_dhp = b.take(td); q.g_df = b.take(td);
+    }
+    L.lnp = b.take((long)B * cfg.n_layers * 4 * D * 4);
     L.total = b.off;
 }
 
@@ -290,6 +296,35 @@ int HeadPlan::backward(int B, int P, int nP, const float* rows, const int32_t* t
     // ---- encoder ----
     float* dX = F(L.t2);
     if ((rc = mask_rows(dHID, tok_row, dX, B, S, D, st))) return rc;
+    if (fused_encoder && encoder_fused_ok(S, D, H, cfg.n_layers, cfg.norm_first)) {
+        // chain kernel (one workgroup per event) + grouped weight-gradient launch; dX is rewritten in place (t3 -> t2 not needed)
+        EncFusedBwdArgs a{};
+        a.dY = dX; a.dX = F(L.t3); a.lnp = F(L.lnp); a.B = B; a.S = S; a.H = H; a.L = cfg.n_layers; a.gelu = cfg.gelu;
+        a.drop_p = dp; a.seed = seed;
+        EncWgradArgs w{};
+        w.T = T; w.B = B; w.L = cfg.n_layers; w.lnp = F(L.lnp);
+        int nj = 0, nt = 0;
+        for (int l = 0; l < cfg.n_layers; ++l) {
+            const HLayer& W = layers[l];
+            const HLayBuf& q = L.lay[l];
+            a.w[l] = EncLayerW{data[W.win], data[W.bin], data[W.wo], data[W.bo], data[W.w1], data[W.b1], data[W.w2], data[W.b2],
+                               data[W.g1], data[W.be1], data[W.g2], data[W.be2]};
+            a.buf[l] = EncLayerBuf{F(q.qkv), F(q.probs), F(q.ctx), F(q.xh1), F(q.rstd1), F(q.x1), F(q.hpre), F(q.hact), F(q.xh2),
+                                   F(q.rstd2), F(L.X[l + 1])};
+            a.g[l] = EncLayerGrad{F(q.g_dqkv), F(q.g_dao), F(q.g_dhp), F(q.g_df)};
+            w.job[nj++] = EncWgradJob{F(q.g_dqkv), 3 * D, F(L.X[l]), grad[W.win], grad[W.bin], 3 * D / 32};
+            w.job[nj++] = EncWgradJob{F(q.g_dao), D, F(q.ctx), grad[W.wo], grad[W.bo], D / 32};
+            w.job[nj++] = EncWgradJob{F(q.g_dhp), D, F(q.x1), grad[W.w1], grad[W.b1], D / 32};
+            w.job[nj++] = EncWgradJob{F(q.g_df), D, F(q.hact), grad[W.w2], grad[W.b2], D / 32};
+            nt += 3 * D / 32 + 3 * (D / 32);
+            w.ln_dst[l][0] = grad[W.g1]; w.ln_dst[l][1] = grad[W.be1]; w.ln_dst[l][2] = grad[W.g2]; w.ln_dst[l][3] = grad[W.be2];
+        }
+        w.n_jobs = nj; w.n_tiles = nt;
+        if ((rc = encoder_fused_bwd(a, w, st))) return rc;
+        dX = F(L.t3);
+        goto combined;
+    }
+    {
     float* d1 = F(L.t3);
     float* dR = F(L.t0);
     float* dT = F(L.t1);
@@ -313,6 +348,8 @@ int HeadPlan::backward(int B, int P, int nP, const float* rows, const int32_t* t
         if ((rc = linear_bwd_dw(dR, 3 * D, F(L.X[l]), D, grad[W.win], grad[W.bin], T, 3 * D, D, st))) return rc;
         if ((rc = linear_bwd_dx(dR, 3 * D, data[W.win], dX, D, T, 3 * D, D, 1, st))) return rc;
     }
+    }
+combined:
     // ---- combined embedding ----
     if ((rc = scatter_tokens_bwd(dX, tok_row, F(L.dC), B, S, D, st))) return rc;
     {

@@ -47,6 +47,20 @@ struct EncFusedArgs {
 };
 bool encoder_fused_ok(int S, int D, int H, int L, int norm_first);
 int encoder_fused_fwd(const EncFusedArgs& a, hipStream_t st);
+// Fused backward: the chain kernel's per-layer outputs (GEMM operands of the weight gradients) and the grouped weight-gradient launch
+struct EncLayerGrad { float *dqkv, *dao, *dhp, *df; };      // [T][3D], [T][D], [T][D], [T][D]
+struct EncFusedBwdArgs {
+    const float* dY; float* dX; float* lnp;                  // dY / dX [T][D]; lnp [B][L][4][D] per-event LayerNorm sums (g1, b1, g2, b2)
+    int B, S, H, L, gelu; float drop_p; uint64_t seed;
+    EncLayerW w[ENC_MAX_LAYERS]; EncLayerBuf buf[ENC_MAX_LAYERS]; EncLayerGrad g[ENC_MAX_LAYERS];
+};
+struct EncWgradJob { const float* dY; int ldy; const float* X; float* dW; float* db; int tiles; };     // tiles = N / 32
+struct EncWgradArgs {
+    int T, B, L, n_jobs, n_tiles; const float* lnp;
+    float* ln_dst[ENC_MAX_LAYERS][4];
+    EncWgradJob job[4 * ENC_MAX_LAYERS];
+};
+int encoder_fused_bwd(const EncFusedBwdArgs& a, const EncWgradArgs& w, hipStream_t st);
 
 int focal_i64(const float* logits, const int64_t* targets, int rows, int C, float gamma, float weight, float* dlogits, float* out,
               hipStream_t st);

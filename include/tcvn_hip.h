@@ -136,9 +136,10 @@ int tcvn_head_num_slots(const tcvn_head* p);
 int tcvn_head_slot(const tcvn_head* p, int i, char* name, int name_cap, int64_t* numel, int* kind);
 int tcvn_head_bind(tcvn_head* p, void* const* data, void* const* grad);
 int64_t tcvn_head_workspace_bytes(const tcvn_head* p, int batch, int max_prongs, int n_prongs);
-/* The encoder stack runs as ONE launch (one workgroup per event, csrc/encoder_fused.hip) when hidden_dim == 128, heads in
- * {4,8,16}, 1 + max_prongs <= 22 and <= 8 layers; otherwise, or after tcvn_head_set_fused_encoder(p, 0), layer by layer on the
- * row kernels.  Both fill the same workspace buffers, so tcvn_head_backward is unaffected.  On by default. */
+/* The encoder stack runs as ONE launch forward (one workgroup per event, csrc/encoder_fused.hip) and TWO launches backward (the
+ * data-gradient chain + a grouped weight-gradient GEMM) when hidden_dim == 128, heads in {4,8}, 1 + max_prongs <= 22 and <= 8
+ * layers; otherwise, or after tcvn_head_set_fused_encoder(p, 0), layer by layer on the row kernels.  Both forwards fill the same
+ * workspace buffers, so either backward follows either forward.  On by default. */
 void tcvn_head_set_fused_encoder(tcvn_head* p, int on);
 
 /* rows [batch + n_prongs, in_dim] fp32: event rows first, then packed prong rows (already concatenated with the
