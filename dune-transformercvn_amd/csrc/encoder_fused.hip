@@ -1,50 +1,80 @@
-// Fused transformer-encoder forward: ONE launch for all layers, one 256-thread workgroup per event.
+// Fused transformer encoder: ONE launch for the forward of all layers and TWO for the backward (the
+// data-gradient chain + a grouped weight-gradient GEMM), one 256-thread workgroup per event.
 // Reference: torch.nn.TransformerEncoderLayer (post-norm, math attention path) as instantiated at
-// transformercvn/network/layers/prong_custom_bert_encoder.py:45-54,57-75.
+// transformercvn/network/layers/prong_custom_bert_encoder.py:45-54,57-75, and its autograd.
 //
-// An event's (1 + P) <= 22 tokens x 128 features live in LDS for the whole stack; every 128 x 128 weight block is streamed
-// from L2 through registers into a padded LDS image (prefetched one block ahead, under the previous block's arithmetic and
-// the attention / LayerNorm phases) and consumed by exact fp32 FMA chains (k ascending, like the row GEMM it replaces).
-// Everything the backward pass reads (qkv, attention probabilities, ctx, LayerNorm xhat / rstd, FFN pre-activation ...) is
-// written to the same workspace buffers the unfused kernels of encoder.hip fill, so either forward can feed the backward.
-// Dropout masks are the same stateless draws (stream ids 0x6000 + 8 l + {0,1,2,3}, element index of the sequence-major row).
+// An event's (1 + P) <= 22 tokens x 128 features live in LDS for the whole stack; every weight block is streamed from L2
+// through registers into a padded LDS image (prefetched one block ahead, under the previous block's arithmetic and the
+// attention / LayerNorm phases) and consumed by exact fp32 FMA chains.  Thread (c, g): output column c = tid & 127, token rows
+// g, g+2, ... ; the row count per thread NR is a template parameter (rows beyond the sequence are zero padding in LDS), so the
+// inner loops carry no predicates.  Dropout masks are the same stateless draws as in encoder.hip (stream ids 0x6000 + 8 l +
+// {0,1,2,3}, element index of the sequence-major row), evaluated by rolled loops into an LDS mask buffer.
+// Everything the backward reads is written to the workspace buffers the unfused kernels of encoder.hip fill, so either forward
+// can feed either backward.
 #include "tcvn_encoder.h"
 
 namespace tcvn {
 
 namespace {
 
-constexpr int D = 128, WLD = 132, QLD = 388, RMAX = 11, SMAX = 2 * RMAX;
+constexpr int D = 128, WLD = 132, QLD = 388, SMAX = 22, HR = 64;
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 
-__device__ __forceinline__ void w_issue(const float* __restrict__ W, float4 (&reg)[16]) {      // 128 rows x 128 floats, row stride 128
+template <int NV>
+__device__ __forceinline__ void w_issue(const float* __restrict__ W, float4 (&reg)[NV]) {      // NV*8 rows x 128 floats, row stride 128
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + 256 * i;
         reg[i] = *reinterpret_cast<const float4*>(W + (idx >> 5) * D + (idx & 31) * 4);
     }
 }
-__device__ __forceinline__ void w_commit(float* Wl, const float4 (&reg)[16]) {
+template <int NV>
+__device__ __forceinline__ void w_commit(float* Wl, const float4 (&reg)[NV]) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + 256 * i;
         *reinterpret_cast<float4*>(Wl + (idx >> 5) * WLD + (idx & 31) * 4) = reg[i];
     }
 }
-// acc[i] = sum_k xin[g + 2 i][k] * Wl[c][k]   (thread: column c = tid & 127, row group g = tid >> 7)
-__device__ __forceinline__ void gemm128(const float* xin, int ldx, int nrows, int g, const float* Wl, int c, float (&acc)[RMAX]) {
+// forward product: acc[i] = sum_k xin[g + 2 i][k] * Wl[c][k]
+template <int NR>
+__device__ __forceinline__ void gemm128(const float* xin, int ldx, int g, const float* Wl, int c, float (&acc)[NR]) {
 #pragma unroll
-    for (int i = 0; i < RMAX; ++i) acc[i] = 0.f;
+    for (int i = 0; i < NR; ++i) acc[i] = 0.f;
     const float* wrow = Wl + c * WLD;
+    const float* xr = xin + g * ldx;
+#pragma unroll 2
     for (int k = 0; k < D; k += 4) {
         const float4 w = *reinterpret_cast<const float4*>(wrow + k);
 #pragma unroll
-        for (int i = 0; i < RMAX; ++i)
-            if (i < nrows) {
-                const float4 x = *reinterpret_cast<const float4*>(xin + (g + 2 * i) * ldx + k);
-                acc[i] = fmaf(x.x, w.x, acc[i]); acc[i] = fmaf(x.y, w.y, acc[i]);
-                acc[i] = fmaf(x.z, w.z, acc[i]); acc[i] = fmaf(x.w, w.w, acc[i]);
-            }
+        for (int i = 0; i < NR; ++i) {
+            const float4 x = *reinterpret_cast<const float4*>(xr + 2 * i * ldx + k);
+            acc[i] = fmaf(x.x, w.x, acc[i]); acc[i] = fmaf(x.y, w.y, acc[i]);
+            acc[i] = fmaf(x.z, w.z, acc[i]); acc[i] = fmaf(x.w, w.w, acc[i]);
+        }
+    }
+}
+// transposed product over one 64-row half block: acc[i] += sum_{n < 64} dy[g + 2 i][n0 + n] * Wl[n][k]
+template <int NR>
+__device__ __forceinline__ void gemm_t64(const float* dy, int ldy, int n0, int g, const float* Wl, int k, float (&acc)[NR]) {
+    const float* yr = dy + g * ldy + n0;
+#pragma unroll 2
+    for (int n = 0; n < HR; n += 4) {
+        const float w0 = Wl[(n + 0) * WLD + k], w1 = Wl[(n + 1) * WLD + k], w2 = Wl[(n + 2) * WLD + k], w3 = Wl[(n + 3) * WLD + k];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const float4 y = *reinterpret_cast<const float4*>(yr + 2 * i * ldy + n);
+            acc[i] = fmaf(y.x, w0, acc[i]); acc[i] = fmaf(y.y, w1, acc[i]);
+            acc[i] = fmaf(y.z, w2, acc[i]); acc[i] = fmaf(y.w, w3, acc[i]);
+        }
+    }
+}
+// mask[s][c] = dropout keep-scale of element (t = s*B + b, c) of a [T][D] site
+__device__ __forceinline__ void fill_mask(float* mask, int S, int B, int b, float dp, uint64_t seed, uint32_t sid) {
+#pragma unroll 1
+    for (int i = threadIdx.x; i < S * D; i += 256) {
+        const int s = i >> 7, c = i & 127;
+        mask[i] = drop_scale(dp, seed, sid, ((uint64_t)s * B + b) * D + c);
     }
 }
 
@@ -52,6 +82,8 @@ __device__ __forceinline__ void gemm128(const float* xin, int ldx, int nrows, in
 __device__ __forceinline__ void ln_rows(const float* y, int S, int B, int b, const float* gamma, const float* beta, float eps, float* out,
                                         float* outg, float* xhg, float* rstdg) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float g0 = gamma[lane], g1 = gamma[lane + 64], b0 = beta[lane], b1 = beta[lane + 64];
+#pragma unroll 1
     for (int s = wave; s < S; s += 4) {
         const float v0 = y[s * D + lane], v1 = y[s * D + lane + 64];
         const float mean = wave_sum(v0 + v1) / D;
@@ -59,7 +91,7 @@ __device__ __forceinline__ void ln_rows(const float* y, int S, int B, int b, con
         const float rstd = rsqrtf(wave_sum(c0 * c0 + c1 * c1) / D + eps);
         const long t = (long)s * B + b;
         const float h0 = c0 * rstd, h1 = c1 * rstd;
-        const float o0 = h0 * gamma[lane] + beta[lane], o1 = h1 * gamma[lane + 64] + beta[lane + 64];
+        const float o0 = h0 * g0 + b0, o1 = h1 * g1 + b1;
         out[s * D + lane] = o0; out[s * D + lane + 64] = o1;
         if (outg) { outg[t * D + lane] = o0; outg[t * D + lane + 64] = o1; }
         if (xhg) { xhg[t * D + lane] = h0; xhg[t * D + lane + 64] = h1; }
@@ -67,239 +99,175 @@ __device__ __forceinline__ void ln_rows(const float* y, int S, int B, int b, con
     }
 }
 
-template <int HD>
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+template <int HD, int NR>
 __global__ __launch_bounds__(256, 1) void k_encoder_fwd(const EncFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SP = 2 * NR, H = D / HD;          // padded rows
     const int S = a.S, B = a.B, b = blockIdx.x, tid = threadIdx.x;
     float* Wl = lds;                         // [128][WLD]
-    float* xin = Wl + D * WLD;               // [S][D]   layer input
-    float* qkv = xin + S * D;                // [S][QLD] q | k | v, later the pre-LayerNorm sums
-    float* ctx = qkv + S * QLD;              // [S][D]
-    float* x1 = ctx + S * D;                 // [S][D]
-    float* hb = x1 + S * D;                  // [S][D]   FFN activation
-    int* valid = reinterpret_cast<int*>(hb + S * D);
+    float* xin = Wl + D * WLD;               // [SP][D]   layer input
+    float* qkv = xin + SP * D;               // [SP][QLD] q | k | v, later the pre-LayerNorm sums ([SP][D])
+    float* ctx = qkv + SP * QLD;             // [SP][D]
+    float* x1 = ctx + SP * D;                // [SP][D]
+    float* hb = x1 + SP * D;                 // [SP][D]   FFN activation
+    float* mask = hb + SP * D;               // [SP][D]   dropout keep-scales of the site being applied
+    float* sc = x1;                          // [H][S][S + 1] attention probabilities: x1 | hb are dead while attention runs (their
+                                             // padding rows may keep scores afterwards: rows >= S never reach a real row)
+    int* valid = reinterpret_cast<int*>(mask + SP * D);
+    static_assert(H * SMAX * (SMAX + 1) <= 2 * 2 * 11 * D, "score buffer must fit x1 | hb at the largest bucket");
     const int c = tid & 127, g = tid >> 7;
-    const int nrows = (S - g + 1) / 2;       // rows g, g+2, ... < S
-    constexpr int hd = HD;
-    const int H = D / HD;
     const float dp = a.drop_p;
-    for (int i = tid; i < S * D; i += 256) {
-        const int s = i / D, d = i - s * D;
-        xin[i] = a.X0[((long)s * B + b) * D + d];
+    for (int i = tid; i < SP * D; i += 256) {
+        const int s = i >> 7, d = i & 127;
+        xin[i] = s < S ? a.X0[((long)s * B + b) * D + d] : 0.f;
+        ctx[i] = 0.f; x1[i] = 0.f; hb[i] = 0.f; mask[i] = 1.f;
     }
-    if (tid < S) valid[tid] = a.tok_row[b * S + tid] >= 0;
+    if (tid < SMAX) valid[tid] = tid < S ? a.tok_row[b * S + tid] >= 0 : 0;
     float4 wreg[16];
-    float acc[RMAX];
-    w_issue(a.w[0].win, wreg);
+    float acc[NR];
+    w_issue<16>(a.w[0].win, wreg);
+#pragma unroll 1
     for (int l = 0; l < a.L; ++l) {
-        const EncLayerW& W = a.w[l];
-        const EncLayerBuf& O = a.buf[l];
+        const EncLayerW W = a.w[l];
+        const EncLayerBuf O = a.buf[l];
         const uint32_t sid = 0x6000u + l * 8;
         // ---- q, k, v projections -------------------------------------------------------------------------------------
 #pragma unroll 1
         for (int ch = 0; ch < 3; ++ch) {
             __syncthreads();
-            w_commit(Wl, wreg);
+            w_commit<16>(Wl, wreg);
             __syncthreads();
-            w_issue(ch < 2 ? W.win + (ch + 1) * D * D : W.wo, wreg);
-            gemm128(xin, D, nrows, g, Wl, c, acc);
+            w_issue<16>(ch < 2 ? W.win + (ch + 1) * D * D : W.wo, wreg);
+            gemm128<NR>(xin, D, g, Wl, c, acc);
             const float bias = W.bin[ch * D + c];
 #pragma unroll
-            for (int i = 0; i < RMAX; ++i)
-                if (i < nrows) {
-                    const int s = g + 2 * i;
-                    const float v = acc[i] + bias;
-                    qkv[s * QLD + ch * D + c] = v;
-                    if (a.save) O.qkv[((long)s * B + b) * 3 * D + ch * D + c] = v;
-                }
+            for (int i = 0; i < NR; ++i) {
+                const int s = g + 2 * i;
+                const float v = acc[i] + bias;
+                qkv[s * QLD + ch * D + c] = v;
+                if (s < S && a.save) O.qkv[((long)s * B + b) * 3 * D + ch * D + c] = v;
+            }
         }
         __syncthreads();
-        // ---- attention: thread (h, s) ----------------------------------------------------------------------------------
+        // ---- attention: thread (h, s); probabilities through LDS ----------------------------------------------------------
         if (tid < H * S) {
             const int s = tid % S, h = tid / S;
-            const float scale = rsqrtf((float)hd);
-            const float* q = qkv + s * QLD + h * hd;
+            const float scale = rsqrtf((float)HD);
             float qs[HD];
 #pragma unroll
-            for (int e = 0; e < HD; ++e) qs[e] = q[e] * scale;
-            float sc[SMAX];                                   // fully unrolled below: stays in registers
+            for (int e = 0; e < HD; ++e) qs[e] = qkv[s * QLD + h * HD + e] * scale;
+            float* p = sc + (h * S + s) * (S + 1);
             float mx = -INFINITY;
+#pragma unroll 1
+            for (int j = 0; j < S; ++j) {
+                const float* kk = qkv + j * QLD + D + h * HD;
+                float d = 0.f;
 #pragma unroll
-            for (int j = 0; j < SMAX; ++j) {
-                sc[j] = -INFINITY;
-                if (j < S) {
-                    const float* k = qkv + j * QLD + D + h * hd;
-                    float d = 0.f;
-#pragma unroll
-                    for (int e = 0; e < HD; ++e) d = fmaf(qs[e], k[e], d);
-                    sc[j] = valid[j] ? d : -INFINITY;
-                    mx = fmaxf(mx, sc[j]);
-                }
+                for (int e = 0; e < HD; ++e) d = fmaf(qs[e], kk[e], d);
+                d = valid[j] ? d : -INFINITY;
+                p[j] = d;
+                mx = fmaxf(mx, d);
             }
             float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < SMAX; ++j)
-                if (j < S) { sc[j] = valid[j] ? expf(sc[j] - mx) : 0.f; sum += sc[j]; }
+#pragma unroll 1
+            for (int j = 0; j < S; ++j) { const float e = valid[j] ? expf(p[j] - mx) : 0.f; p[j] = e; sum += e; }
             const float inv = 1.0f / sum;
             float cx[HD];
 #pragma unroll
             for (int e = 0; e < HD; ++e) cx[e] = 0.f;
             float* P = a.save ? O.probs + (((long)b * H + h) * S + s) * S : nullptr;
+#pragma unroll 1
+            for (int j = 0; j < S; ++j) {
+                float pr = p[j] * inv;
+                if (P) P[j] = pr;
+                if (dp > 0.f) pr *= drop_scale(dp, a.seed, sid, (((uint64_t)b * H + h) * S + s) * S + j);
+                const float* v = qkv + j * QLD + 2 * D + h * HD;
 #pragma unroll
-            for (int j = 0; j < SMAX; ++j)
-                if (j < S) {
-                    float p = sc[j] * inv;
-                    if (P) P[j] = p;
-                    if (dp > 0.f) p *= drop_scale(dp, a.seed, sid, (((uint64_t)b * H + h) * S + s) * S + j);
-                    const float* v = qkv + j * QLD + 2 * D + h * hd;
-#pragma unroll
-                    for (int e = 0; e < HD; ++e) cx[e] = fmaf(p, v[e], cx[e]);
-                }
+                for (int e = 0; e < HD; ++e) cx[e] = fmaf(pr, v[e], cx[e]);
+            }
 #pragma unroll
             for (int e = 0; e < HD; ++e) {
-                ctx[s * D + h * hd + e] = cx[e];
-                if (a.save) O.ctx[((long)s * B + b) * D + h * hd + e] = cx[e];
+                ctx[s * D + h * HD + e] = cx[e];
+                if (a.save) O.ctx[((long)s * B + b) * D + h * HD + e] = cx[e];
             }
         }
+        if (dp > 0.f) fill_mask(mask, S, B, b, dp, a.seed, sid + 1);
         // ---- out_proj + residual + LayerNorm 1 ---------------------------------------------------------------------------
         __syncthreads();
-        w_commit(Wl, wreg);
+        w_commit<16>(Wl, wreg);
         __syncthreads();
-        w_issue(W.w1, wreg);
-        gemm128(ctx, D, nrows, g, Wl, c, acc);
+        w_issue<16>(W.w1, wreg);
+        gemm128<NR>(ctx, D, g, Wl, c, acc);
         {
             const float bias = W.bo[c];
 #pragma unroll
-            for (int i = 0; i < RMAX; ++i)
-                if (i < nrows) {
-                    const int s = g + 2 * i;
-                    float r = acc[i] + bias;
-                    if (dp > 0.f) r *= drop_scale(dp, a.seed, sid + 1, ((uint64_t)s * B + b) * D + c);
-                    qkv[s * D + c] = xin[s * D + c] + r;                 // q|k|v are dead: reuse as the [S][D] sum buffer
-                }
+            for (int i = 0; i < NR; ++i) {
+                const int s = g + 2 * i;
+                const float r = (acc[i] + bias) * mask[s * D + c];
+                qkv[s * D + c] = xin[s * D + c] + r;                 // q|k|v are dead: reuse as the [SP][D] sum buffer
+            }
         }
         __syncthreads();
         ln_rows(qkv, S, B, b, W.g1, W.be1, a.eps, x1, a.save ? O.x1 : nullptr, a.save ? O.xh1 : nullptr, a.save ? O.rstd1 : nullptr);
+        if (dp > 0.f) fill_mask(mask, S, B, b, dp, a.seed, sid + 2);
         // ---- FFN -----------------------------------------------------------------------------------------------------------
         __syncthreads();
-        w_commit(Wl, wreg);
+        w_commit<16>(Wl, wreg);
         __syncthreads();
-        w_issue(W.w2, wreg);
-        gemm128(x1, D, nrows, g, Wl, c, acc);
+        w_issue<16>(W.w2, wreg);
+        gemm128<NR>(x1, D, g, Wl, c, acc);
         {
             const float bias = W.b1[c];
 #pragma unroll
-            for (int i = 0; i < RMAX; ++i)
-                if (i < nrows) {
-                    const int s = g + 2 * i;
-                    const float x = acc[i] + bias;
-                    const long t = (long)s * B + b;
-                    if (a.save) O.hpre[t * D + c] = x;
-                    float y = a.gelu ? 0.5f * x * (1.f + erff(x * kInvSqrt2)) : fmaxf(x, 0.f);
-                    if (dp > 0.f) y *= drop_scale(dp, a.seed, sid + 2, (uint64_t)t * D + c);
+            for (int i = 0; i < NR; ++i) {
+                const int s = g + 2 * i;
+                const float x = acc[i] + bias;
+                const float y = (a.gelu ? 0.5f * x * (1.f + erff(x * kInvSqrt2)) : fmaxf(x, 0.f)) * mask[s * D + c];
+                if (s < S) {
                     hb[s * D + c] = y;
-                    if (a.save) O.hact[t * D + c] = y;
+                    if (a.save) { const long t = (long)s * B + b; O.hpre[t * D + c] = x; O.hact[t * D + c] = y; }
                 }
+            }
         }
         __syncthreads();
-        w_commit(Wl, wreg);
+        if (dp > 0.f) fill_mask(mask, S, B, b, dp, a.seed, sid + 3);
+        w_commit<16>(Wl, wreg);
         __syncthreads();
-        if (l + 1 < a.L) w_issue(a.w[l + 1].win, wreg);
-        gemm128(hb, D, nrows, g, Wl, c, acc);
+        if (l + 1 < a.L) w_issue<16>(a.w[l + 1].win, wreg);
+        gemm128<NR>(hb, D, g, Wl, c, acc);
         {
             const float bias = W.b2[c];
 #pragma unroll
-            for (int i = 0; i < RMAX; ++i)
-                if (i < nrows) {
-                    const int s = g + 2 * i;
-                    float r = acc[i] + bias;
-                    if (dp > 0.f) r *= drop_scale(dp, a.seed, sid + 3, ((uint64_t)s * B + b) * D + c);
-                    qkv[s * D + c] = x1[s * D + c] + r;
-                }
+            for (int i = 0; i < NR; ++i) {
+                const int s = g + 2 * i;
+                const float r = (acc[i] + bias) * mask[s * D + c];
+                qkv[s * D + c] = x1[s * D + c] + r;
+            }
         }
         __syncthreads();
         ln_rows(qkv, S, B, b, W.g2, W.be2, a.eps, xin, O.xnext, a.save ? O.xh2 : nullptr, a.save ? O.rstd2 : nullptr);
     }
     __syncthreads();
     for (int i = tid; i < S * D; i += 256) {                              // hidden * sequence_mask (:73)
-        const int s = i / D, d = i - s * D;
+        const int s = i >> 7, d = i & 127;
         a.HID[((long)s * B + b) * D + d] = valid[s] ? xin[i] : 0.f;
     }
 }
 
-}  // namespace
-
-bool encoder_fused_ok(int S, int Dm, int H, int L, int norm_first) {
-    return Dm == D && (H == 4 || H == 8) && S >= 1 && S <= SMAX && L >= 1 && L <= ENC_MAX_LAYERS && !norm_first;
-}
-
-int encoder_fused_fwd(const EncFusedArgs& a, hipStream_t st) {
-    if (!encoder_fused_ok(a.S, D, a.H, a.L, 0)) return -2;
-    const size_t smem = ((size_t)D * WLD + (size_t)a.S * (4 * D + QLD)) * 4 + (size_t)a.S * 4 + 64;
-    static bool attr = false;
-    if (!attr) {
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_fwd<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_fwd<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_fwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
-    if (smem > 160 * 1024) return -2;
-    if (a.H == 4) hipLaunchKernelGGL(k_encoder_fwd<32>, dim3(a.B), dim3(256), smem, st, a);
-    else if (a.H == 8) hipLaunchKernelGGL(k_encoder_fwd<16>, dim3(a.B), dim3(256), smem, st, a);
-    else hipLaunchKernelGGL(k_encoder_fwd<8>, dim3(a.B), dim3(256), smem, st, a);
-    TCVN_LAUNCH_CHECK();
-    return 0;
-}
-
-}  // namespace tcvn
-
 // =====================================================================================================================
-// Fused encoder BACKWARD: one launch for the data-gradient chain of all layers (one workgroup per event, gradients of an
-// event's tokens in LDS), one launch for every weight / bias / LayerNorm gradient (k_encoder_wgrad: a grouped TN GEMM over the
-// T = S*B token rows, single writer per element -> deterministic, no atomics).  The chain kernel leaves the per-layer GEMM
-// operands (d qkv, d attention-out, d FFN pre-activation, d FFN out) and per-event LayerNorm partial sums in the workspace.
-// Reads exactly what either forward saved.  Autograd of torch.nn.TransformerEncoderLayer (post-norm), same call sites as above.
+// backward chain
 // =====================================================================================================================
-namespace tcvn {
-namespace {
-
-constexpr int HR = 64;          // rows of a weight half-block staged at a time (dX = dY W contracts over W's rows)
-
-__device__ __forceinline__ void wh_issue(const float* __restrict__ W, float4 (&reg)[8]) {       // 64 rows x 128 floats
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = threadIdx.x + 256 * i;
-        reg[i] = *reinterpret_cast<const float4*>(W + (idx >> 5) * D + (idx & 31) * 4);
-    }
-}
-__device__ __forceinline__ void wh_commit(float* Wl, const float4 (&reg)[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = threadIdx.x + 256 * i;
-        *reinterpret_cast<float4*>(Wl + (idx >> 5) * WLD + (idx & 31) * 4) = reg[i];
-    }
-}
-// acc[i] += sum_{n < 64} dy[g + 2 i][n0 + n] * Wl[n][k]
-__device__ __forceinline__ void gemm_t64(const float* dy, int ldy, int n0, int nrows, int g, const float* Wl, int k, float (&acc)[RMAX]) {
-    for (int n = 0; n < HR; n += 4) {
-        const float w0 = Wl[(n + 0) * WLD + k], w1 = Wl[(n + 1) * WLD + k], w2 = Wl[(n + 2) * WLD + k], w3 = Wl[(n + 3) * WLD + k];
-#pragma unroll
-        for (int i = 0; i < RMAX; ++i)
-            if (i < nrows) {
-                const float4 y = *reinterpret_cast<const float4*>(dy + (g + 2 * i) * ldy + n0 + n);
-                acc[i] = fmaf(y.x, w0, acc[i]); acc[i] = fmaf(y.y, w1, acc[i]);
-                acc[i] = fmaf(y.z, w2, acc[i]); acc[i] = fmaf(y.w, w3, acc[i]);
-            }
-    }
-}
-
-// LayerNorm backward of the rows in `dy` (LDS): ds -> `res` (LDS, the residual branch) and drop * ds -> `br` (LDS) + `brg` (global).
+// LayerNorm backward of the rows in `dy` (LDS): ds -> `res` (LDS, the residual branch) and mask * ds -> `br` (LDS) + `brg` (global).
 // Per-event column sums of dy*xhat and dy go to lnp[0][c], lnp[1][c] (global, this event's slice) via `red` (LDS, 4 x 256 floats).
 __device__ __forceinline__ void ln_bwd_rows(const float* dy, int S, int B, int b, const float* gamma, const float* xhg, const float* rstdg,
-                                            float* res, float* br, float* brg, float dp, uint64_t seed, uint32_t sid, float* red, float* lnp) {
+                                            float* res, float* br, float* brg, const float* mask, float* red, float* lnp) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float ga0 = 0.f, ga1 = 0.f, be0 = 0.f, be1 = 0.f;
     const float g0 = gamma[lane], g1 = gamma[lane + 64];
+#pragma unroll 1
     for (int s = wave; s < S; s += 4) {
         const long t = (long)s * B + b;
         const float y0 = dy[s * D + lane], y1 = dy[s * D + lane + 64];
@@ -310,154 +278,155 @@ __device__ __forceinline__ void ln_bwd_rows(const float* dy, int S, int B, int b
         const float rstd = rstdg[t];
         const float d0 = rstd * (a0 - s1 - h0 * s2), d1 = rstd * (a1 - s1 - h1 * s2);
         res[s * D + lane] = d0; res[s * D + lane + 64] = d1;
-        float r0 = d0, r1 = d1;
-        if (dp > 0.f) { r0 *= drop_scale(dp, seed, sid, (uint64_t)t * D + lane); r1 *= drop_scale(dp, seed, sid, (uint64_t)t * D + lane + 64); }
+        const float r0 = d0 * mask[s * D + lane], r1 = d1 * mask[s * D + lane + 64];
         br[s * D + lane] = r0; br[s * D + lane + 64] = r1;
         brg[t * D + lane] = r0; brg[t * D + lane + 64] = r1;
     }
     red[wave * 256 + lane] = ga0; red[wave * 256 + 64 + lane] = ga1; red[wave * 256 + 128 + lane] = be0; red[wave * 256 + 192 + lane] = be1;
     __syncthreads();
-    {
-        const int i = threadIdx.x;                       // 0..127: dgamma column, 128..255: dbeta column
-        const float v = red[i] + red[256 + i] + red[512 + i] + red[768 + i];
-        lnp[i] = v;
-    }
+    const int i = threadIdx.x;                           // 0..127: dgamma column, 128..255: dbeta column
+    lnp[i] = red[i] + red[256 + i] + red[512 + i] + red[768 + i];
 }
 
-template <int HD>
+template <int HD, int NR>
 __global__ __launch_bounds__(256, 1) void k_encoder_bwd(const EncFusedBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SP = 2 * NR, H = D / HD;
     const int S = a.S, B = a.B, b = blockIdx.x, tid = threadIdx.x;
     float* Wl = lds;                         // [64][WLD]; doubles as the dS / Pd exchange and the LayerNorm reduction scratch
-    float* bA = Wl + HR * WLD;               // [S][D]
-    float* bB = bA + S * D;                  // [S][D]
-    float* bC = bB + S * D;                  // [S][D]
-    float* bQ = bC + S * D;                  // [S][QLD] saved q | k | v
-    float* bDQ = bQ + S * QLD;               // [S][QLD] d(q | k | v)
+    float* bA = Wl + HR * WLD;               // [SP][D]
+    float* bB = bA + SP * D;                 // [SP][D]
+    float* bC = bB + SP * D;                 // [SP][D]
+    float* bQ = bC + SP * D;                 // [SP][QLD] saved q | k | v
+    float* bDQ = bQ + SP * QLD;              // [SP][QLD] d(q | k | v)
+    float* mask = bDQ + SP * QLD;            // [SP][D]
     const int k = tid & 127, g = tid >> 7;
-    const int nrows = (S - g + 1) / 2;
-    constexpr int hd = HD;
-    const int H = D / HD;
     const float dp = a.drop_p;
-    for (int i = tid; i < S * D; i += 256) {
-        const int s = i / D, d = i - s * D;
-        bA[i] = a.dY[((long)s * B + b) * D + d];
+    for (int i = tid; i < SP * D; i += 256) {
+        const int s = i >> 7, d = i & 127;
+        bA[i] = s < S ? a.dY[((long)s * B + b) * D + d] : 0.f;
+        bB[i] = 0.f; bC[i] = 0.f; mask[i] = 1.f;
     }
+    for (int i = tid; i < SP * QLD; i += 256) bDQ[i] = 0.f;
     float4 wreg[8];
-    float acc[RMAX];
-    wh_issue(a.w[a.L - 1].w2, wreg);
+    float acc[NR];
+    w_issue<8>(a.w[a.L - 1].w2, wreg);
     __syncthreads();
+#pragma unroll 1
     for (int l = a.L - 1; l >= 0; --l) {
-        const EncLayerW& W = a.w[l];
-        const EncLayerBuf& O = a.buf[l];
-        const EncLayerGrad& G = a.g[l];
+        const EncLayerW W = a.w[l];
+        const EncLayerBuf O = a.buf[l];
+        const EncLayerGrad G = a.g[l];
         const uint32_t sid = 0x6000u + l * 8;
         float* lnp = a.lnp + ((long)b * a.L + l) * 4 * D;
         // ---- LayerNorm 2 backward: bA = d x_{l+1} -> bB = d x1 (residual), bC = d f (dropped) -----------------------------------
-        ln_bwd_rows(bA, S, B, b, W.g2, O.xh2, O.rstd2, bB, bC, G.df, dp, a.seed, sid + 3, Wl, lnp + 2 * D);
+        if (dp > 0.f) { fill_mask(mask, S, B, b, dp, a.seed, sid + 3); __syncthreads(); }
+        ln_bwd_rows(bA, S, B, b, W.g2, O.xh2, O.rstd2, bB, bC, G.df, mask, Wl, lnp + 2 * D);
         // ---- d hact = d f W2 ; d hpre = d hact * drop * act'(hpre) -> bA -------------------------------------------------------
+        __syncthreads();
+        if (dp > 0.f) fill_mask(mask, S, B, b, dp, a.seed, sid + 2);
 #pragma unroll
-        for (int i = 0; i < RMAX; ++i) acc[i] = 0.f;
+        for (int i = 0; i < NR; ++i) acc[i] = 0.f;
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
             __syncthreads();
-            wh_commit(Wl, wreg);
+            w_commit<8>(Wl, wreg);
             __syncthreads();
-            wh_issue(hf == 0 ? W.w2 + HR * D : W.w1, wreg);
-            gemm_t64(bC, D, hf * HR, nrows, g, Wl, k, acc);
+            w_issue<8>(hf == 0 ? W.w2 + HR * D : W.w1, wreg);
+            gemm_t64<NR>(bC, D, hf * HR, g, Wl, k, acc);
         }
 #pragma unroll
-        for (int i = 0; i < RMAX; ++i)
-            if (i < nrows) {
-                const int s = g + 2 * i;
+        for (int i = 0; i < NR; ++i) {
+            const int s = g + 2 * i;
+            if (s < S) {
                 const long t = (long)s * B + b;
                 const float x = O.hpre[t * D + k];
-                float gr = acc[i];
-                if (dp > 0.f) gr *= drop_scale(dp, a.seed, sid + 2, (uint64_t)t * D + k);
+                const float gr = acc[i] * mask[s * D + k];
                 const float dact = a.gelu ? 0.5f * (1.f + erff(x * kInvSqrt2)) + x * 0.3989422804014327f * expf(-0.5f * x * x) : (x > 0.f ? 1.f : 0.f);
                 const float v = gr * dact;
                 bA[s * D + k] = v;
                 G.dhp[t * D + k] = v;
             }
+        }
         // ---- d x1 += d hpre W1 -------------------------------------------------------------------------------------------------
 #pragma unroll
-        for (int i = 0; i < RMAX; ++i) acc[i] = 0.f;
+        for (int i = 0; i < NR; ++i) acc[i] = 0.f;
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
             __syncthreads();
-            wh_commit(Wl, wreg);
+            w_commit<8>(Wl, wreg);
             __syncthreads();
-            wh_issue(hf == 0 ? W.w1 + HR * D : W.wo, wreg);
-            gemm_t64(bA, D, hf * HR, nrows, g, Wl, k, acc);
+            w_issue<8>(hf == 0 ? W.w1 + HR * D : W.wo, wreg);
+            gemm_t64<NR>(bA, D, hf * HR, g, Wl, k, acc);
         }
 #pragma unroll
-        for (int i = 0; i < RMAX; ++i)
-            if (i < nrows) bB[(g + 2 * i) * D + k] += acc[i];
+        for (int i = 0; i < NR; ++i) bB[(g + 2 * i) * D + k] += acc[i];
+        if (dp > 0.f) fill_mask(mask, S, B, b, dp, a.seed, sid + 1);
         __syncthreads();
         // ---- LayerNorm 1 backward: bB = d x1 -> bA = d x_l (residual), bC = d attention-out (dropped) ---------------------------
-        ln_bwd_rows(bB, S, B, b, W.g1, O.xh1, O.rstd1, bA, bC, G.dao, dp, a.seed, sid + 1, Wl, lnp);
+        ln_bwd_rows(bB, S, B, b, W.g1, O.xh1, O.rstd1, bA, bC, G.dao, mask, Wl, lnp);
         // ---- d ctx = d ao Wo -> bB ; meanwhile the saved q | k | v come in ---------------------------------------------------
+#pragma unroll 1
         for (int i = tid; i < S * 3 * D; i += 256) {
             const int s = i / (3 * D), d = i - s * 3 * D;
             bQ[s * QLD + d] = O.qkv[((long)s * B + b) * 3 * D + d];
         }
 #pragma unroll
-        for (int i = 0; i < RMAX; ++i) acc[i] = 0.f;
+        for (int i = 0; i < NR; ++i) acc[i] = 0.f;
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
             __syncthreads();
-            wh_commit(Wl, wreg);
+            w_commit<8>(Wl, wreg);
             __syncthreads();
-            wh_issue(hf == 0 ? W.wo + HR * D : W.win, wreg);
-            gemm_t64(bC, D, hf * HR, nrows, g, Wl, k, acc);
+            w_issue<8>(hf == 0 ? W.wo + HR * D : W.win, wreg);
+            gemm_t64<NR>(bC, D, hf * HR, g, Wl, k, acc);
         }
 #pragma unroll
-        for (int i = 0; i < RMAX; ++i)
-            if (i < nrows) bB[(g + 2 * i) * D + k] = acc[i];
+        for (int i = 0; i < NR; ++i) bB[(g + 2 * i) * D + k] = acc[i];
         __syncthreads();
         // ---- attention backward: thread (h, s); dS and the dropped probabilities are exchanged through the W image ---------------
-        float* xS = Wl;                                   // [H][S][SMAX + 1]
-        float* xP = Wl + H * S * (SMAX + 1);              // [H][S][SMAX + 1]   (2 * 8 * 22 * 23 floats <= 64 * 132)
+        float* xS = Wl;                                   // [H][SMAX][SMAX + 1]
+        float* xP = Wl + H * SMAX * (SMAX + 1);           // [H][SMAX][SMAX + 1]   (2 * 8 * 22 * 23 floats <= 64 * 132)
         if (tid < H * S) {
             const int s = tid % S, h = tid / S;
             const float* P = O.probs + (((long)b * H + h) * S + s) * S;
             float dc[HD];
 #pragma unroll
-            for (int e = 0; e < HD; ++e) dc[e] = bB[s * D + h * hd + e];
-            float dpj[SMAX], pj[SMAX];
+            for (int e = 0; e < HD; ++e) dc[e] = bB[s * D + h * HD + e];
+            float* rS = xS + (h * SMAX + s) * (SMAX + 1);
+            float* rP = xP + (h * SMAX + s) * (SMAX + 1);
             float dot = 0.f;
+#pragma unroll 1
+            for (int j = 0; j < S; ++j) {
+                const float* v = bQ + j * QLD + 2 * D + h * HD;
+                float gsum = 0.f;
 #pragma unroll
-            for (int j = 0; j < SMAX; ++j) {
-                dpj[j] = 0.f; pj[j] = 0.f;
-                if (j < S) {
-                    const float* v = bQ + j * QLD + 2 * D + h * hd;
-                    float gsum = 0.f;
-#pragma unroll
-                    for (int e = 0; e < HD; ++e) gsum = fmaf(dc[e], v[e], gsum);
-                    float m = 1.f;
-                    if (dp > 0.f) m = drop_scale(dp, a.seed, sid, (((uint64_t)b * H + h) * S + s) * S + j);
-                    pj[j] = P[j];
-                    xP[(h * S + s) * (SMAX + 1) + j] = pj[j] * m;
-                    dpj[j] = gsum * m;
-                    dot = fmaf(dpj[j], pj[j], dot);
-                }
+                for (int e = 0; e < HD; ++e) gsum = fmaf(dc[e], v[e], gsum);
+                float m = 1.f;
+                if (dp > 0.f) m = drop_scale(dp, a.seed, sid, (((uint64_t)b * H + h) * S + s) * S + j);
+                const float pj = P[j];
+                rP[j] = pj * m;
+                const float dpj = gsum * m;
+                rS[j] = dpj;                                     // dP for now
+                dot = fmaf(dpj, pj, dot);
             }
-#pragma unroll
-            for (int j = 0; j < SMAX; ++j)
-                if (j < S) xS[(h * S + s) * (SMAX + 1) + j] = pj[j] * (dpj[j] - dot);
+#pragma unroll 1
+            for (int j = 0; j < S; ++j) rS[j] = P[j] * (rS[j] - dot);
         }
         __syncthreads();
         if (tid < H * S) {
             const int s = tid % S, h = tid / S;
-            const float scale = rsqrtf((float)hd);
+            const float scale = rsqrtf((float)HD);
             float dq[HD], dk[HD], dv[HD];
 #pragma unroll
             for (int e = 0; e < HD; ++e) { dq[e] = 0.f; dk[e] = 0.f; dv[e] = 0.f; }
+#pragma unroll 1
             for (int j = 0; j < S; ++j) {
-                const float dsj = xS[(h * S + s) * (SMAX + 1) + j], dst = xS[(h * S + j) * (SMAX + 1) + s], pdt = xP[(h * S + j) * (SMAX + 1) + s];
-                const float* kj = bQ + j * QLD + D + h * hd;
-                const float* qj = bQ + j * QLD + h * hd;
-                const float* dcj = bB + j * D + h * hd;
+                const float dsj = xS[(h * SMAX + s) * (SMAX + 1) + j], dst = xS[(h * SMAX + j) * (SMAX + 1) + s];
+                const float pdt = xP[(h * SMAX + j) * (SMAX + 1) + s];
+                const float* kj = bQ + j * QLD + D + h * HD;
+                const float* qj = bQ + j * QLD + h * HD;
+                const float* dcj = bB + j * D + h * HD;
 #pragma unroll
                 for (int e = 0; e < HD; ++e) {
                     dq[e] = fmaf(dsj, kj[e], dq[e]);
@@ -465,33 +434,32 @@ __global__ __launch_bounds__(256, 1) void k_encoder_bwd(const EncFusedBwdArgs a)
                     dv[e] = fmaf(pdt, dcj[e], dv[e]);
                 }
             }
-            float* og = G.dqkv + ((long)s * B + b) * 3 * D + h * hd;
+            float* og = G.dqkv + ((long)s * B + b) * 3 * D + h * HD;
 #pragma unroll
             for (int e = 0; e < HD; ++e) {
                 const float q = dq[e] * scale, kk = dk[e] * scale;
-                bDQ[s * QLD + h * hd + e] = q; bDQ[s * QLD + D + h * hd + e] = kk; bDQ[s * QLD + 2 * D + h * hd + e] = dv[e];
+                bDQ[s * QLD + h * HD + e] = q; bDQ[s * QLD + D + h * HD + e] = kk; bDQ[s * QLD + 2 * D + h * HD + e] = dv[e];
                 og[e] = q; og[D + e] = kk; og[2 * D + e] = dv[e];
             }
         }
         // ---- d x_l = bA + d qkv Win (six half blocks) ------------------------------------------------------------------------------
 #pragma unroll
-        for (int i = 0; i < RMAX; ++i) acc[i] = 0.f;
+        for (int i = 0; i < NR; ++i) acc[i] = 0.f;
 #pragma unroll 1
         for (int hf = 0; hf < 6; ++hf) {
             __syncthreads();
-            wh_commit(Wl, wreg);
+            w_commit<8>(Wl, wreg);
             __syncthreads();
-            if (hf < 5) wh_issue(W.win + (hf + 1) * HR * D, wreg);
-            else if (l > 0) wh_issue(a.w[l - 1].w2, wreg);
-            gemm_t64(bDQ, QLD, hf * HR, nrows, g, Wl, k, acc);
+            if (hf < 5) w_issue<8>(W.win + (hf + 1) * HR * D, wreg);
+            else if (l > 0) w_issue<8>(a.w[l - 1].w2, wreg);
+            gemm_t64<NR>(bDQ, QLD, hf * HR, g, Wl, k, acc);
         }
 #pragma unroll
-        for (int i = 0; i < RMAX; ++i)
-            if (i < nrows) bA[(g + 2 * i) * D + k] += acc[i];
+        for (int i = 0; i < NR; ++i) bA[(g + 2 * i) * D + k] += acc[i];
         __syncthreads();
     }
     for (int i = tid; i < S * D; i += 256) {
-        const int s = i / D, d = i - s * D;
+        const int s = i >> 7, d = i & 127;
         a.dX[((long)s * B + b) * D + d] = bA[i];
     }
 }
@@ -499,7 +467,7 @@ __global__ __launch_bounds__(256, 1) void k_encoder_bwd(const EncFusedBwdArgs a)
 // ---- grouped weight gradients: dW[n][k] += sum_t dY[t][n] X[t][k], db[n] += sum_t dY[t][n]; LayerNorm parameter sums ----------------
 __global__ __launch_bounds__(256) void k_encoder_wgrad(const EncWgradArgs a) {
     __shared__ float Xs[32][D];
-    __shared__ float Ys[32][2][16];
+    __shared__ __attribute__((aligned(16))) float Ys[32][2][16];
     const int tid = threadIdx.x;
     int blk = blockIdx.x;
     if (blk >= a.n_tiles) {                                        // LayerNorm parameter gradients: sum the per-event partials
@@ -524,7 +492,7 @@ __global__ __launch_bounds__(256) void k_encoder_wgrad(const EncWgradArgs a) {
     for (int t0 = 0; t0 < a.T; t0 += 32) {
         __syncthreads();
         for (int i = tid; i < 32 * D; i += 256) {
-            const int t = i / D, c = i - t * D;
+            const int t = i >> 7, c = i & 127;
             Xs[t][c] = t0 + t < a.T ? J.X[(long)(t0 + t) * D + c] : 0.f;
         }
         for (int i = tid; i < 32 * 32; i += 256) {
@@ -550,23 +518,60 @@ __global__ __launch_bounds__(256) void k_encoder_wgrad(const EncWgradArgs a) {
     if (tid < 32) J.db[n0 + tid] += bsum;
 }
 
+// rows per thread for a sequence of S tokens: the smallest instantiated bucket
+int rows_bucket(int S) { const int r = (S + 1) / 2; return r <= 3 ? 3 : r <= 5 ? 5 : r <= 8 ? 8 : 11; }
+
+template <int HD, int NR>
+int launch_fwd(const EncFusedArgs& a, hipStream_t st) {
+    constexpr int SP = 2 * NR, H = D / HD;
+    const size_t smem = ((size_t)D * WLD + (size_t)SP * (5 * D + QLD)) * 4 + SMAX * 4 + 64;
+    if (H * a.S * (a.S + 1) > 2 * SP * D) return -2;
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_fwd<HD, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    if (smem > 160 * 1024) return -2;
+    hipLaunchKernelGGL((k_encoder_fwd<HD, NR>), dim3(a.B), dim3(256), smem, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+template <int HD, int NR>
+int launch_bwd(const EncFusedBwdArgs& a, hipStream_t st) {
+    constexpr int SP = 2 * NR;
+    const size_t smem = ((size_t)HR * WLD + (size_t)SP * (4 * D + 2 * QLD)) * 4 + 64;
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_bwd<HD, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    if (smem > 160 * 1024) return -2;
+    hipLaunchKernelGGL((k_encoder_bwd<HD, NR>), dim3(a.B), dim3(256), smem, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
+
+bool encoder_fused_ok(int S, int Dm, int H, int L, int norm_first) {
+    return Dm == D && (H == 4 || H == 8) && S >= 1 && S <= SMAX && L >= 1 && L <= ENC_MAX_LAYERS && !norm_first;
+}
+
+int encoder_fused_fwd(const EncFusedArgs& a, hipStream_t st) {
+    if (!encoder_fused_ok(a.S, D, a.H, a.L, 0)) return -2;
+    const int nr = rows_bucket(a.S);
+    if (a.H == 8) return nr == 3 ? launch_fwd<16, 3>(a, st) : nr == 5 ? launch_fwd<16, 5>(a, st) : nr == 8 ? launch_fwd<16, 8>(a, st) : launch_fwd<16, 11>(a, st);
+    return nr == 3 ? launch_fwd<32, 3>(a, st) : nr == 5 ? launch_fwd<32, 5>(a, st) : nr == 8 ? launch_fwd<32, 8>(a, st) : launch_fwd<32, 11>(a, st);
+}
 
 int encoder_fused_bwd(const EncFusedBwdArgs& a, const EncWgradArgs& w, hipStream_t st) {
     if (!encoder_fused_ok(a.S, D, a.H, a.L, 0)) return -2;
-    const size_t smem = ((size_t)HR * WLD + (size_t)a.S * (3 * D + 2 * QLD)) * 4 + 64;
-    static bool attr = false;
-    if (!attr) {
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_bwd<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_bwd<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
-    if (smem > 160 * 1024 || 2 * a.H * a.S * (SMAX + 1) > HR * WLD) return -2;
-    if (a.H == 4) hipLaunchKernelGGL(k_encoder_bwd<32>, dim3(a.B), dim3(256), smem, st, a);
-    else if (a.H == 8) hipLaunchKernelGGL(k_encoder_bwd<16>, dim3(a.B), dim3(256), smem, st, a);
-    else hipLaunchKernelGGL(k_encoder_bwd<8>, dim3(a.B), dim3(256), smem, st, a);
-    TCVN_LAUNCH_CHECK();
+    if (2 * a.H * SMAX * (SMAX + 1) > HR * WLD) return -2;
+    const int nr = rows_bucket(a.S);
+    int rc;
+    if (a.H == 8) rc = nr == 3 ? launch_bwd<16, 3>(a, st) : nr == 5 ? launch_bwd<16, 5>(a, st) : nr == 8 ? launch_bwd<16, 8>(a, st) : launch_bwd<16, 11>(a, st);
+    else rc = nr == 3 ? launch_bwd<32, 3>(a, st) : nr == 5 ? launch_bwd<32, 5>(a, st) : nr == 8 ? launch_bwd<32, 8>(a, st) : launch_bwd<32, 11>(a, st);
+    if (rc) return rc;
     const int ln_blocks = cdiv((long)a.L * 4 * D, 256);
     hipLaunchKernelGGL(k_encoder_wgrad, dim3(w.n_tiles + ln_blocks), dim3(256), 0, st, w);
     TCVN_LAUNCH_CHECK();
