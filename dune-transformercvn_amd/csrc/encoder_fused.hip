@@ -21,19 +21,19 @@ constexpr int D = 128, WLD = 132, QLD = 388, SMAX = 22, HR = 64;
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 
 template <int NV>
-__device__ __forceinline__ void w_issue(const float* __restrict__ W, float4 (&reg)[NV]) {      // NV*8 rows x 128 floats, row stride 128
+__device__ __forceinline__ void w_issue(const float* __restrict__ W, f32x4 (&reg)[NV]) {      // NV*8 rows x 128 floats, row stride 128
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + 256 * i;
-        reg[i] = *reinterpret_cast<const float4*>(W + (idx >> 5) * D + (idx & 31) * 4);
+        reg[i] = *reinterpret_cast<const f32x4*>(W + (idx >> 5) * D + (idx & 31) * 4);
     }
 }
 template <int NV>
-__device__ __forceinline__ void w_commit(float* Wl, const float4 (&reg)[NV]) {
+__device__ __forceinline__ void w_commit(float* Wl, const f32x4 (&reg)[NV]) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + 256 * i;
-        *reinterpret_cast<float4*>(Wl + (idx >> 5) * WLD + (idx & 31) * 4) = reg[i];
+        *reinterpret_cast<f32x4*>(Wl + (idx >> 5) * WLD + (idx & 31) * 4) = reg[i];
     }
 }
 // forward product: acc[i] = sum_k xin[g + 2 i][k] * Wl[c][k]
@@ -45,10 +45,10 @@ __device__ __forceinline__ void gemm128(const float* xin, int ldx, int g, const 
     const float* xr = xin + g * ldx;
 #pragma unroll 2
     for (int k = 0; k < D; k += 4) {
-        const float4 w = *reinterpret_cast<const float4*>(wrow + k);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + k);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const float4 x = *reinterpret_cast<const float4*>(xr + 2 * i * ldx + k);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xr + 2 * i * ldx + k);
             acc[i] = fmaf(x.x, w.x, acc[i]); acc[i] = fmaf(x.y, w.y, acc[i]);
             acc[i] = fmaf(x.z, w.z, acc[i]); acc[i] = fmaf(x.w, w.w, acc[i]);
         }
@@ -63,7 +63,7 @@ __device__ __forceinline__ void gemm_t64(const float* dy, int ldy, int n0, int g
         const float w0 = Wl[(n + 0) * WLD + k], w1 = Wl[(n + 1) * WLD + k], w2 = Wl[(n + 2) * WLD + k], w3 = Wl[(n + 3) * WLD + k];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const float4 y = *reinterpret_cast<const float4*>(yr + 2 * i * ldy + n);
+            const f32x4 y = *reinterpret_cast<const f32x4*>(yr + 2 * i * ldy + n);
             acc[i] = fmaf(y.x, w0, acc[i]); acc[i] = fmaf(y.y, w1, acc[i]);
             acc[i] = fmaf(y.z, w2, acc[i]); acc[i] = fmaf(y.w, w3, acc[i]);
         }
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void k_encoder_fwd(const EncFusedArgs a) {
         ctx[i] = 0.f; x1[i] = 0.f; hb[i] = 0.f; mask[i] = 1.f;
     }
     if (tid < SMAX) valid[tid] = tid < S ? a.tok_row[b * S + tid] >= 0 : 0;
-    float4 wreg[16];
+    f32x4 wreg[16];
     float acc[NR];
     w_issue<16>(a.w[0].win, wreg);
 #pragma unroll 1
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void k_encoder_bwd(const EncFusedBwdArgs a)
         bB[i] = 0.f; bC[i] = 0.f; mask[i] = 1.f;
     }
     for (int i = tid; i < SP * QLD; i += 256) bDQ[i] = 0.f;
-    float4 wreg[8];
+    f32x4 wreg[8];
     float acc[NR];
     w_issue<8>(a.w[a.L - 1].w2, wreg);
     __syncthreads();
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void k_encoder_wgrad(const EncWgradArgs a) {
             const float x = Xs[t][k];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 y = *reinterpret_cast<const float4*>(&Ys[t][g][q * 4]);
+                const f32x4 y = *reinterpret_cast<const f32x4*>(&Ys[t][g][q * 4]);
                 acc[q * 4 + 0] = fmaf(y.x, x, acc[q * 4 + 0]); acc[q * 4 + 1] = fmaf(y.y, x, acc[q * 4 + 1]);
                 acc[q * 4 + 2] = fmaf(y.z, x, acc[q * 4 + 2]); acc[q * 4 + 3] = fmaf(y.w, x, acc[q * 4 + 3]);
             }
