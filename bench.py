@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=None, help="override options.dropout (experiments only; the metric uses the file's 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--bwd-overlap", action="store_true", help="A/B: weight-gradient kernels on a side stream (tcvn_backward_overlap(1))")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing (fp32_ms_per_step)")
     ap.add_argument("--dump-records", default="", help="write every profiled launch (name, ms, flops) to this JSON file")
     args = ap.parse_args()
@@ -225,6 +226,8 @@ def main():
     model.train()
     rt = model.network.hip_runtime()
     rt.ensure_bound()
+    if args.bwd_overlap:
+        _lib.lib.tcvn_backward_overlap(1)
     batch = make_batch(args.batch, args.prongs, 1234 + rank, dev)
     reducer = GradReducer(rt.flat_grad, rt.segments) if world > 1 else None
     if reducer:

@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
                                 if (PREF) { xv = pxv[i]; gv = pgv[i]; }
                                 else {
                                     xv = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16*>(g.Xin) + px * g.ldxin + ncol);
-                                    gv = *reinterpret_cast<const u16x8*>(gp);
+                                    if (EPI == EPI_DGRAD_POOL && g.g_write) {
+#pragma unroll
+                                        for (int j = 0; j < 8; ++j) gv[j] = 0;
+                                    } else gv = *reinterpret_cast<const u16x8*>(gp);
                                 }
                                 u16x8 o;
 #pragma unroll
@@ -287,6 +290,37 @@ int gemm_nt_nblk(const GemmNtArgs& a) {
     const long mt = (a.M + rows - 1) / rows;
     return (int)(mt < cap ? mt : cap);
 }
+namespace {
+__global__ void k_zero_pool_remainder(bf16* G, long ld, int n_img, int Hin, int Win, int Hc, int Wc) {
+    // one thread per (remainder pixel, 8-channel chunk)
+    const int rows_extra = Hin - Hc, cols_extra = Win - Wc;
+    const long per_img = (long)rows_extra * Win + (long)Hc * cols_extra;
+    const long chunks = ld / 8;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_img * per_img * chunks) return;
+    const long px = i / chunks; const int ch = (int)(i - px * chunks);
+    const int img = (int)(px / per_img); long r = px - (long)img * per_img;
+    int y, x;
+    if (r < (long)rows_extra * Win) { y = Hc + (int)(r / Win); x = (int)(r % Win); }
+    else { r -= (long)rows_extra * Win; y = (int)(r / cols_extra); x = Wc + (int)(r % cols_extra); }
+    u16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = 0;
+    *reinterpret_cast<u16x8*>(G + (((long)img * Hin + y) * Win + x) * ld + ch * 8) = z;
+}
+}  // namespace
+
+int zero_pool_remainder(void* G, long ld, int n_img, int Hin, int Win, int Ho, int Wo, hipStream_t st) {
+    const int Hc = 2 * Ho, Wc = 2 * Wo;
+    const long per_img = (long)(Hin - Hc) * Win + (long)Hc * (Win - Wc);
+    if (per_img <= 0 || n_img <= 0) return 0;
+    if (ld % 8) return -2;
+    const long total = n_img * per_img * (ld / 8);
+    hipLaunchKernelGGL(k_zero_pool_remainder, dim3(cdiv(total, 256)), dim3(256), 0, st, reinterpret_cast<bf16*>(G), ld, n_img, Hin, Win, Hc, Wc);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
 int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
     if (a.M <= 0) return 0;
     if (!gemm_nt_ok(a)) return -2;

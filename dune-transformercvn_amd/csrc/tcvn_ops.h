@@ -194,9 +194,13 @@ struct GemmNtArgs {
                                                                    // channels >= Kreal are zeroed
     const void* Xin; long ldxin; const float *sc, *sh, *sl;        // EPI_DGRAD*: BatchNorm input + its table
     void* Gout; long ldgo;
+    int g_write;                             // EPI_DGRAD_POOL: this launch is the FIRST contribution to Gout: write, do not read-add
+                                             // (pixels outside every 2x2 window are zeroed by zero_pool_remainder)
     int H, W, Hin, Win;                      // EPI_DGRAD_POOL geometry (rows = pooled pixels H x W of inputs Hin x Win)
     double* part; int nblk;                  // [nblk][N][2 (fwd) | 3 (dgrad)]
 };
+// rows >= 2*Ho and columns >= 2*Wo of an [n, Hin, Win, ld] bf16 map := 0 (the pixels a floor-mode 2x2 pooling never reads)
+int zero_pool_remainder(void* G, long ld, int n_img, int Hin, int Win, int Ho, int Wo, hipStream_t st);
 bool gemm_nt_ok(const GemmNtArgs& a);
 int gemm_nt_nblk(const GemmNtArgs& a);
 int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st);
