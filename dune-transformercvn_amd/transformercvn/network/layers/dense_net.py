@@ -32,12 +32,21 @@ class Bottleneck(nn.Module):
         self.output_block = _holder(norm2=nn.BatchNorm2d(mid), relu2=nn.PReLU(mid),
                                     conv2=nn.Conv2d(mid, growth_rate, kernel_size=3, padding=1), dropout=nn.Dropout(dropout))
 
+    def forward(self, x: Tensor) -> Tensor:
+        """ATen execution of the holder modules -- reached only through torch.jit.script export (see DenseNet.forward)."""
+        return torch.cat((x, self.output_block(self.bottleneck_block(x))), dim=1)
+
 
 class DenseBlock(nn.Module):
     def __init__(self, num_layers: int, input_features: int, batch_norm_size: int, growth_rate: int, dropout: float) -> None:
         super().__init__()
         self.layers = nn.ModuleList(Bottleneck(input_features + i * growth_rate, growth_rate, batch_norm_size, dropout)
                                     for i in range(num_layers))
+
+    def forward(self, x: Tensor) -> Tensor:
+        for layer in self.layers:
+            x = layer(x)
+        return x
 
 
 class Transition(nn.Sequential):
@@ -90,9 +99,16 @@ class DenseNet(nn.Module):
     def batch_norms(self):
         return [m for m in self.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
 
-    def forward(self, x) -> Tensor:
-        """Stand-alone inference/training-forward of the embedder (no autograd): ``x`` is a SparsePixels bundle or a
-        dense NCHW map on the GPU.  Inside the full network the fused runtime drives the same engine instead."""
+    def forward(self, x: Tensor) -> Tensor:
+        """Eager: the gfx950 engine (``x`` is a SparsePixels bundle or a dense NCHW map on the GPU; no autograd, no CPU fallback).
+        Under ``torch.jit.script`` (CreateCompiled.ipynb cells 6-14: TorchScript export for CPU inference in LArSoft) the holder
+        modules are real torch modules with the reference's parameters, so the exported graph runs them through ATen."""
+        if torch.jit.is_scripting():
+            return self.output_block(self.condense(self.features(x)))
+        return self._hip_forward(x)
+
+    @torch.jit.unused
+    def _hip_forward(self, x: Tensor) -> Tensor:
         if not isinstance(x, SparsePixels):
             x = SparsePixels.from_dense(x)
         if not x.coords.is_cuda:

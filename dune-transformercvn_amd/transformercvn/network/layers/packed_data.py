@@ -10,7 +10,7 @@ from torch import Tensor
 
 def pack_indices(mask: Tensor) -> Tuple[Tensor, Tensor]:
     """I1 = event index, I2 = slot index of every true mask entry, row-major."""
-    nz = mask.nonzero(as_tuple=False)
+    nz = torch.nonzero(mask)
     return nz[:, 0], nz[:, 1]
 
 
@@ -20,7 +20,7 @@ def masked_pack_1d_precomputed(data: Tensor, mask: Tensor) -> Tuple[Tensor, Tens
 
 
 def masked_pad_1d_precomputed(packed_data: Tensor, I1: Tensor, I2: Tensor, batch_size: int, max_length: int) -> Tensor:
-    out = packed_data.new_zeros(batch_size, max_length, packed_data.shape[1])
+    out = torch.zeros(batch_size, max_length, packed_data.shape[1], dtype=packed_data.dtype, device=packed_data.device)
     out[I1, I2] = packed_data
     return out
 

@@ -5,7 +5,10 @@
 reference passes ``hidden_dim`` as ``dim_feedforward``.  Execution: csrc/encoder.hip via the head engine."""
 import warnings
 
-from torch import nn
+from typing import Tuple
+
+import torch
+from torch import Tensor, nn
 
 from transformercvn.options import Options
 
@@ -14,18 +17,28 @@ class ProngCustomBertEncoder(nn.Module):
     def __init__(self, options: Options, hidden_dim: int, num_heads: int, dropout: float, activation: str, norm_first: bool):
         super().__init__()
         self.options = options
-        layer = nn.TransformerEncoderLayer(hidden_dim, num_heads, hidden_dim, dropout, activation, norm_first=norm_first)
+        layer = nn.TransformerEncoderLayer(hidden_dim, num_heads, hidden_dim, dropout, activation, norm_first=bool(norm_first))
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             self.encoder = nn.TransformerEncoder(layer, options.num_encoder_layers)
 
-    def forward(self, embeddings, mask):
+    def forward(self, embeddings: Tensor, mask: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
         """(tokens [B, S, D], mask [B, S] bool) -> (hidden [S, B, D], padding_mask [B, S], sequence_mask [S, B, 1]) like the
-        reference (:57-75), on the encoder stage of the head engine (tcvn_head_encode).  Forward only, no autograd."""
+        reference (:57-75).  Eager: the encoder stage of the head engine (tcvn_head_encode; forward only); scripted: ATen."""
+        batch_size, max_particles, _ = embeddings.shape
+        padding_mask = ~mask
+        sequence_mask = mask.view(batch_size, max_particles, 1).transpose(0, 1).contiguous()
+        if torch.jit.is_scripting():
+            hidden = embeddings.transpose(0, 1).contiguous() * sequence_mask
+            hidden = self.encoder(hidden, src_key_padding_mask=padding_mask) * sequence_mask
+        else:
+            hidden = self._hip_forward(embeddings, mask)
+        return hidden, padding_mask, sequence_mask
+
+    @torch.jit.unused
+    def _hip_forward(self, embeddings: Tensor, mask: Tensor) -> Tensor:
         from transformercvn.hip.owners import owner_of
         net = owner_of(self)
         if net is None:
             raise RuntimeError("ProngCustomBertEncoder.forward needs the owning NeutrinoBaseNetwork (its HIP runtime holds the plan)")
-        hidden = net.hip_runtime().encode(embeddings, mask, self.training)
-        B, S = mask.shape
-        return hidden, ~mask, mask.view(B, S, 1).transpose(0, 1).contiguous()
+        return net.hip_runtime().encode(embeddings, mask, self.training)

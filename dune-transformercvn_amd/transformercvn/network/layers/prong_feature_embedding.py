@@ -20,7 +20,14 @@ class LinearBlock(nn.Module):
         self._fused = isinstance(self.norm, nn.BatchNorm1d) and isinstance(self.activation, nn.PReLU)
 
     def forward(self, x: Tensor) -> Tensor:
-        """Linear -> BatchNorm1d -> PReLU -> Dropout on the row kernels (reference :25-33); forward only, no autograd."""
+        """Linear -> BatchNorm1d -> PReLU -> Dropout (reference :25-33).  Eager: the HIP row kernels (forward only, no autograd);
+        under torch.jit.script (TorchScript export) the holder modules run through ATen."""
+        if torch.jit.is_scripting():
+            return self.dropout(self.activation(self.norm(self.linear(x))))
+        return self._hip_forward(x)
+
+    @torch.jit.unused
+    def _hip_forward(self, x: Tensor) -> Tensor:
         from transformercvn.hip import rowops
         if not self._fused:
             raise NotImplementedError("the MI355X path implements LinearBlock as Linear-BatchNorm1d-PReLU (both option files)")
@@ -52,6 +59,5 @@ class ProngFeatureEmbedding(nn.Module):
 
     def forward(self, data: Tensor, extra: Tensor) -> Tensor:
         if self.disable_smart_features:
-            return data.new_zeros(data.shape[0], self.output_dim)
-        raise NotImplementedError("smart (reconstructed) prong features are not part of the MI355X hot path: both option "
-                                  "files of the reference set disable_smart_features")
+            return torch.zeros(data.shape[0], self.output_dim, dtype=data.dtype, device=data.device)
+        return self.embedding(torch.cat([data, extra], dim=1))          # LinearBlocks: HIP row kernels eagerly, ATen when scripted

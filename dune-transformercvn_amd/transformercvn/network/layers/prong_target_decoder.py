@@ -1,6 +1,7 @@
 """Per-prong classification head (reference: layers/prong_target_decoder.py:8-41): halving Linear-BN-PReLU-Dropout
 blocks down to >= 8 features, then Linear(final, classes)."""
-from torch import nn
+import torch
+from torch import Tensor, nn
 
 from transformercvn.options import Options
 from transformercvn.network.layers.encoder import create_linear_block
@@ -30,9 +31,18 @@ class ProngTargetDecoder(nn.Module):
             width = reported
         return nn.Sequential(*modules), reported, widths
 
-    def forward(self, hidden):
-        """[T, B, hidden_dim] -> [T, B, classes] (reference :34-41): the Linear-BN-PReLU-Dropout blocks and the output layer
-        on the HIP row kernels; BatchNorm1d sees the zeroed padding tokens exactly like the reference.  Forward only."""
+    def forward(self, hidden: Tensor) -> Tensor:
+        """[T, B, hidden_dim] -> [T, B, classes] (reference :34-41): the Linear-BN-PReLU-Dropout blocks and the output layer;
+        BatchNorm1d sees the zeroed padding tokens exactly like the reference.  HIP row kernels eagerly (forward only), ATen when
+        scripted (TorchScript export)."""
+        if torch.jit.is_scripting():
+            T, B, D = hidden.shape
+            h = self.output_layer(self.hidden_layers(hidden.reshape(T * B, D)))
+            return h.reshape(T, B, self.output_dim)
+        return self._hip_forward(hidden)
+
+    @torch.jit.unused
+    def _hip_forward(self, hidden: Tensor) -> Tensor:
         import torch
         from torch import nn
         from transformercvn.hip import rowops

@@ -104,8 +104,13 @@ class SDXLNet(nn.Module):
             self._bound_sig = None
         return self._engine
 
-    def forward(self, x) -> Tensor:
-        """Stand-alone forward of the embedder (no autograd): ``x`` is a SparsePixels bundle or a dense NCHW map on the GPU."""
+    def forward(self, x: Tensor) -> Tensor:
+        """Stand-alone forward of the embedder (no autograd): ``x`` is a SparsePixels bundle or a dense NCHW map on the GPU.
+        (TorchScript export of this embedder is not provided: the reference exports the DenseNet model only, CreateCompiled.ipynb.)"""
+        return self._hip_forward(x)
+
+    @torch.jit.unused
+    def _hip_forward(self, x: Tensor) -> Tensor:
         if not isinstance(x, SparsePixels):
             x = SparsePixels.from_dense(x)
         if not x.coords.is_cuda:

@@ -13,6 +13,7 @@ import torch
 from torch import Tensor, nn
 
 from transformercvn.hip.pixels import SparsePixels
+from transformercvn.network.layers.packed_data import masked_pack_1d_precomputed, masked_pad_1d_precomputed
 from transformercvn.network.layers.prong_custom_bert_encoder import ProngCustomBertEncoder
 from transformercvn.network.layers.prong_decoder import ProngDecoder
 from transformercvn.network.layers.prong_feature_embedding import ProngFeatureEmbedding, LinearBlock
@@ -50,10 +51,31 @@ class BaseProngEmbedding(nn.Module, ABC):
             options, self.feature_embedding_dim + self.pixel_embedding_dim + self.position_embedding_dim, options.hidden_dim)
 
 
-    def forward(self, features: Tensor, extra: Tensor, event_pixels, event_mask: Tensor, prong_pixels, prong_mask: Tensor):
-        """-> (tokens [B, 1+P, hidden], mask [B, 1+P]) like the reference (:87-125): both DenseNets, position embeddings, the
-        shared LinearBlock over event + packed prong rows, masked pad, event token first -- on the two DenseNet engines and
-        the embedding stage of the head engine (tcvn_head_embed).  Forward only, no autograd."""
+    def forward(self, features: Tensor, extra: Tensor, event_pixels: Tensor, event_mask: Tensor, prong_pixels: Tensor,
+                prong_mask: Tensor) -> Tuple[Tensor, Tensor]:
+        """-> (tokens [B, 1+P, hidden], mask [B, 1+P]) like the reference (:87-125): both pixel embedders, position embeddings, the
+        shared LinearBlock over event + packed prong rows, masked pad, event token first.  Eager: the two embedder engines and the
+        embedding stage of the head engine (tcvn_head_embed; pixels may be SparsePixels bundles; forward only, no autograd).
+        Under torch.jit.script (TorchScript export, CreateCompiled.ipynb cells 6-14): the same graph through ATen."""
+        if torch.jit.is_scripting():
+            batch_size, max_prongs, _ = features.shape
+            event_embeddings = torch.cat((self.event_pixel_embedding(event_pixels),
+                                          self.event_position_embedding.expand(batch_size, -1)), dim=1)
+            packed, I1, I2 = masked_pack_1d_precomputed(features, prong_mask)
+            prong_pixel_embeddings = self.prong_pixel_embedding(prong_pixels)
+            # prongs also receive the *event* position embedding (reference quirk, :107)
+            prong_embeddings = torch.cat((self.feature_embedding(packed, extra[I1]), prong_pixel_embeddings,
+                                          self.event_position_embedding.expand(prong_pixel_embeddings.shape[0], -1)), dim=1)
+            combined = self.combined_embedding(torch.cat((event_embeddings, prong_embeddings), dim=0))
+            padded = masked_pad_1d_precomputed(combined[batch_size:], I1, I2, batch_size, max_prongs)
+            tokens = torch.cat((combined[:batch_size].view(batch_size, 1, -1), padded), dim=1)
+        else:
+            tokens = self._hip_forward(features, extra, event_pixels, event_mask, prong_pixels, prong_mask)
+        return tokens, torch.cat((event_mask.to(tokens.device), prong_mask.to(tokens.device)), dim=1)
+
+    @torch.jit.unused
+    def _hip_forward(self, features: Tensor, extra: Tensor, event_pixels: Tensor, event_mask: Tensor, prong_pixels: Tensor,
+                     prong_mask: Tensor) -> Tensor:
         from transformercvn.hip.owners import owner_of
         net = owner_of(self)
         if net is None:
@@ -62,8 +84,7 @@ class BaseProngEmbedding(nn.Module, ABC):
             event_pixels = SparsePixels.from_dense(event_pixels)
         if not isinstance(prong_pixels, SparsePixels):
             prong_pixels = SparsePixels.from_dense(prong_pixels)
-        tokens = net.hip_runtime().embed(features, extra, event_pixels, event_mask, prong_pixels, prong_mask, self.training)
-        return tokens, torch.cat((event_mask.to(tokens.device), prong_mask.to(tokens.device)), dim=1)
+        return net.hip_runtime().embed(features, extra, event_pixels, event_mask, prong_pixels, prong_mask, self.training)
 
 
 class NeutrinoBaseNetwork(nn.Module):
@@ -94,9 +115,19 @@ class NeutrinoBaseNetwork(nn.Module):
                                        seed=int(getattr(self._options, "seed", 0)))
         return self._runtime
 
-    def forward(self, features: Tensor, extra: Tensor, event_pixels, event_mask: Tensor, prong_pixels, prong_mask: Tensor,
-                counts: Optional[Tuple[int, int]] = None) -> Tuple[Tensor, Tensor]:
-        """-> (event_logits [B, Ce], prong_logits [B, P, Cp]); pixels are SparsePixels bundles (or dense NCHW maps)."""
+    def forward(self, features: Tensor, extra: Tensor, event_pixels: Tensor, event_mask: Tensor, prong_pixels: Tensor,
+                prong_mask: Tensor, counts: Optional[Tuple[int, int]] = None) -> Tuple[Tensor, Tensor]:
+        """-> (event_logits [B, Ce], prong_logits [B, P, Cp]) (reference :166-188).  Eager: the fused MI355X step (pixels are
+        SparsePixels bundles or dense NCHW maps).  Under torch.jit.script: the stage modules through ATen (export)."""
+        if torch.jit.is_scripting():
+            tokens, mask = self.prong_embedding(features, extra, event_pixels, event_mask, prong_pixels, prong_mask)
+            hidden, padding_mask, sequence_mask = self.encoder(tokens, mask)
+            return self.event_decoder(hidden[0]), self.prong_decoder(hidden[1:]).transpose(0, 1)
+        return self._hip_forward(features, extra, event_pixels, event_mask, prong_pixels, prong_mask, counts)
+
+    @torch.jit.unused
+    def _hip_forward(self, features: Tensor, extra: Tensor, event_pixels: Tensor, event_mask: Tensor, prong_pixels: Tensor,
+                     prong_mask: Tensor, counts: Optional[Tuple[int, int]] = None) -> Tuple[Tensor, Tensor]:
         if not isinstance(event_pixels, SparsePixels):
             event_pixels = SparsePixels.from_dense(event_pixels)
         if not isinstance(prong_pixels, SparsePixels):
