@@ -65,6 +65,15 @@ __global__ void k_scatter(const ScatterArgs a) {
     const int img = a.coords[i * 3], y = a.coords[i * 3 + 1], x = a.coords[i * 3 + 2];
     if (img < 0 || img >= a.n_img || y < 0 || y >= a.H || x < 0 || x >= a.W) return;
     T* o = reinterpret_cast<T*>(a.img) + (((long)img * a.H + y) * a.W + x) * a.Cpix;
+    if (a.log_pixels == 3) {       // one_hot_pixels (reference :47-52): F.one_hot(values.long(), 256) per value channel, no scaling, no noise
+        const int F = a.Cpix / 256;
+        for (int f = 0; f < F; ++f) {
+            int v = (int)a.values[i * F + f];
+            v = v < 0 ? 0 : v > 255 ? 255 : v;
+            o[f * 256 + v] = from_f<T>(1.f);
+        }
+        return;
+    }
     for (int c = 0; c < a.Cpix; ++c) {
         float v = a.values[i * a.Cpix + c];
         v = a.log_pixels == 1 ? logf(v + 1.f) : a.log_pixels == 0 ? v / 255.0f : v;   // 2: already preprocessed

@@ -269,6 +269,21 @@ __global__ void k_permute_rows(const float* in, float* out, int B, int P, int C,
     if (to_bm) { const int b = r / P, p = r - b * P; out[i] = in[((long)p * B + b) * C + c]; }
     else { const int p = r / B, b = r - p * B; out[i] = in[((long)b * P + p) * C + c]; }
 }
+// pre-norm residual: y = x + drop(r)   /   its backward branch: dr = drop * dy
+__global__ void k_add_drop(const float* x, const float* r, float* y, long n, float drop_p, uint64_t seed, uint32_t stream_id) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = r[i];
+    if (drop_p > 0.f) v *= drop_scale(drop_p, seed, stream_id, (uint64_t)i);
+    y[i] = x[i] + v;
+}
+__global__ void k_mul_drop(const float* dy, float* dr, long n, float drop_p, uint64_t seed, uint32_t stream_id) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = dy[i];
+    if (drop_p > 0.f) v *= drop_scale(drop_p, seed, stream_id, (uint64_t)i);
+    dr[i] = v;
+}
 __global__ void k_add_inplace(float* dst, const float* src, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += src[i];
@@ -279,6 +294,14 @@ __global__ void k_add_inplace(float* dst, const float* src, long n) {
 int permute_rows(const float* in, float* out, int B, int P, int C, int to_bm, hipStream_t st) {
     if (B * P * C <= 0) return 0;
     hipLaunchKernelGGL(k_permute_rows, dim3(cdiv((long)B * P * C, 256)), dim3(256), 0, st, in, out, B, P, C, to_bm);
+    TCVN_LAUNCH_CHECK(); return 0;
+}
+int add_drop(const float* x, const float* r, float* y, long n, float drop_p, uint64_t seed, uint32_t sid, hipStream_t st) {
+    hipLaunchKernelGGL(k_add_drop, dim3(cdiv(n, 256)), dim3(256), 0, st, x, r, y, n, drop_p, seed, sid);
+    TCVN_LAUNCH_CHECK(); return 0;
+}
+int mul_drop(const float* dy, float* dr, long n, float drop_p, uint64_t seed, uint32_t sid, hipStream_t st) {
+    hipLaunchKernelGGL(k_mul_drop, dim3(cdiv(n, 256)), dim3(256), 0, st, dy, dr, n, drop_p, seed, sid);
     TCVN_LAUNCH_CHECK(); return 0;
 }
 int add_inplace(float* dst, const float* src, long n, hipStream_t st) {

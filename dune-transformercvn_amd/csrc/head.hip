@@ -114,6 +114,7 @@ void HeadPlan::layout(int B, int P, int nP, HLayout& L) const {
         q.qkv = b.take(3 * td); q.probs = b.take((long)B * H * S * S * 4); q.ctx = b.take(td); q.ao = b.take(td);
         q.xh1 = b.take(td); q.rstd1 = b.take((long)T * 4); q.x1 = b.take(td); q.hpre = b.take(td); q.hact = b.take(td);
         q.f = b.take(td); q.xh2 = b.take(td); q.rstd2 = b.take((long)T * 4);
+        q.h1 = cfg.norm_first ? b.take(td) : -1; q.h2 = cfg.norm_first ? b.take(td) : -1;
         L.lay.push_back(q);
     }
     L.HID = b.take(td);
@@ -175,6 +176,31 @@ int HeadPlan::encode(int B, int P, const int32_t* tok_row, char* ws, const HLayo
         }
         return encoder_fused_fwd(a, st);
     }
+    if (cfg.norm_first) {
+        // pre-norm variant (prong_custom_bert_encoder.py:45-52 with transformer_norm_first): x += drop(sa(LN1(x))); x += drop(ff(LN2(x))).
+        // LN(x) is add_ln_fwd with a zero residual branch (t0 is scratch of the backward pass, free here).
+        float* zero = F(L.t0);
+        TCVN_CHECK(hipMemsetAsync(zero, 0, (size_t)T * D * 4, st));
+        for (int l = 0; l < cfg.n_layers; ++l) {
+            const HLayer& W = layers[l];
+            const HLayBuf& q = L.lay[l];
+            const uint32_t sid = 0x6000u + l * 8;
+            AddLnArgs n1{F(L.X[l]), zero, data[W.g1], data[W.be1], F(q.h1), F(q.xh1), F(q.rstd1), T, D, kEps, 0.f, seed, sid + 1};
+            if ((rc = add_ln_fwd(n1, st))) return rc;
+            if ((rc = linear_fwd(F(q.h1), D, data[W.win], data[W.bin], F(q.qkv), 3 * D, T, 3 * D, D, st))) return rc;
+            AttnArgs a{F(q.qkv), tok_row, F(q.probs), F(q.ctx), B, S, H, hd, dp, seed, sid};
+            if ((rc = attn_fwd(a, st))) return rc;
+            if ((rc = linear_fwd(F(q.ctx), D, data[W.wo], data[W.bo], F(q.ao), D, T, D, D, st))) return rc;
+            if ((rc = add_drop(F(L.X[l]), F(q.ao), F(q.x1), (long)T * D, dp, seed, sid + 1, st))) return rc;
+            AddLnArgs n2{F(q.x1), zero, data[W.g2], data[W.be2], F(q.h2), F(q.xh2), F(q.rstd2), T, D, kEps, 0.f, seed, sid + 3};
+            if ((rc = add_ln_fwd(n2, st))) return rc;
+            if ((rc = linear_fwd(F(q.h2), D, data[W.w1], data[W.b1], F(q.hpre), D, T, D, D, st))) return rc;
+            if ((rc = act_fwd(F(q.hpre), F(q.hact), (long)T * D, cfg.gelu, dp, seed, sid + 2, st))) return rc;
+            if ((rc = linear_fwd(F(q.hact), D, data[W.w2], data[W.b2], F(q.f), D, T, D, D, st))) return rc;
+            if ((rc = add_drop(F(q.x1), F(q.f), F(L.X[l + 1]), (long)T * D, dp, seed, sid + 3, st))) return rc;
+        }
+        return mask_rows(F(L.X[cfg.n_layers]), tok_row, F(L.HID), B, S, D, st);
+    }
     for (int l = 0; l < cfg.n_layers; ++l) {
         const HLayer& W = layers[l];
         const HLayBuf& q = L.lay[l];
@@ -222,7 +248,6 @@ int HeadPlan::decode(int B, int P, float* ev_logits, float* pr_logits, char* ws,
 
 int HeadPlan::check(int B, int P, int nP, long ws_bytes, HLayout& L) const {
     if (!bound) return -11;
-    if (cfg.norm_first) { fprintf(stderr, "tcvn: transformer_norm_first is not implemented\n"); return -20; }
     if (cfg.dec_out_in != dec_width) { fprintf(stderr, "tcvn: prong decoder width mismatch (reference would fail too)\n"); return -21; }
     if (B <= 0 || P < 0 || nP < 0 || 1 + P > 64) return -1;          // attention kernel: sequences up to 64 tokens
     layout(B, P, nP, L);
@@ -328,6 +353,35 @@ int HeadPlan::backward(int B, int P, int nP, const float* rows, const int32_t* t
     float* d1 = F(L.t3);
     float* dR = F(L.t0);
     float* dT = F(L.t1);
+    if (cfg.norm_first) {
+        // dX = d x_{l+1}.  d x1 = dX + LN2'(d h2) ; d x_l = d x1 + LN1'(d h1); the dropped branches carry drop * gradient.
+        float* dS = F(L.dHID);                                   // LayerNorm input gradients (dHID is consumed by now)
+        for (int l = cfg.n_layers - 1; l >= 0; --l) {
+            const HLayer& W = layers[l];
+            const HLayBuf& q = L.lay[l];
+            const uint32_t sid = 0x6000u + l * 8;
+            const long n = (long)T * D;
+            if ((rc = mul_drop(dX, dR, n, dp, seed, sid + 3, st))) return rc;                               // dR = d f
+            if ((rc = linear_bwd_dw(dR, D, F(q.hact), D, grad[W.w2], grad[W.b2], T, D, D, st))) return rc;
+            if ((rc = linear_bwd_dx(dR, D, data[W.w2], dT, D, T, D, D, 0, st))) return rc;                  // dT = d hact
+            if ((rc = act_bwd(F(q.hpre), dT, dR, n, cfg.gelu, dp, seed, sid + 2, st))) return rc;           // dR = d hpre
+            if ((rc = linear_bwd_dw(dR, D, F(q.h2), D, grad[W.w1], grad[W.b1], T, D, D, st))) return rc;
+            if ((rc = linear_bwd_dx(dR, D, data[W.w1], dT, D, T, D, D, 0, st))) return rc;                  // dT = d h2
+            AddLnBwdArgs n2{dT, F(q.xh2), F(q.rstd2), data[W.g2], dS, d1, grad[W.g2], grad[W.be2], T, D, 0.f, seed, sid + 3};
+            if ((rc = add_ln_bwd(n2, st))) return rc;                                                       // dS = LN2 input gradient
+            if ((rc = add_inplace(dX, dS, n, st))) return rc;                                               // dX = d x1
+            if ((rc = mul_drop(dX, dR, n, dp, seed, sid + 1, st))) return rc;                               // dR = d ao
+            if ((rc = linear_bwd_dw(dR, D, F(q.ctx), D, grad[W.wo], grad[W.bo], T, D, D, st))) return rc;
+            if ((rc = linear_bwd_dx(dR, D, data[W.wo], dT, D, T, D, D, 0, st))) return rc;                  // dT = d ctx
+            AttnBwdArgs ab{F(q.qkv), F(q.probs), dT, dR, B, S, H, hd, dp, seed, sid};                       // dR = d qkv [T, 3D]
+            if ((rc = attn_bwd(ab, st))) return rc;
+            if ((rc = linear_bwd_dw(dR, 3 * D, F(q.h1), D, grad[W.win], grad[W.bin], T, 3 * D, D, st))) return rc;
+            if ((rc = linear_bwd_dx(dR, 3 * D, data[W.win], dT, D, T, 3 * D, D, 0, st))) return rc;         // dT = d h1
+            AddLnBwdArgs n1{dT, F(q.xh1), F(q.rstd1), data[W.g1], dS, d1, grad[W.g1], grad[W.be1], T, D, 0.f, seed, sid + 1};
+            if ((rc = add_ln_bwd(n1, st))) return rc;
+            if ((rc = add_inplace(dX, dS, n, st))) return rc;                                               // dX = d x_l
+        }
+    } else
     for (int l = cfg.n_layers - 1; l >= 0; --l) {
         const HLayer& W = layers[l];
         const HLayBuf& q = L.lay[l];
@@ -467,6 +521,28 @@ extern "C" int tcvn_rows_bn_prelu_forward(const float* x, int64_t ldx, int rows,
     r.save_mean = save_mean_rstd; r.save_rstd = save_mean_rstd + channels; r.train = train; r.eps = kEps; r.momentum = kMom;
     r.drop_p = train ? drop_p : 0.f; r.seed = seed; r.stream_id = stream_id;
     return rows_bn_fwd(r, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Backward of the two row operators (smart-feature MLP, layers/prong_feature_embedding.py:36-78: the only LinearBlocks outside the head plan)
+extern "C" int tcvn_linear_backward(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* weight, float* dx, int64_t lddx,
+                                    float* dweight, float* dbias, int rows, int n_out, int n_in, void* stream) {
+    if (!dy || !x || !weight || rows <= 0 || n_out <= 0 || n_in <= 0) return -1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    if (dweight && (rc = linear_bwd_dw(dy, lddy, x, ldx, dweight, dbias, rows, n_out, n_in, st))) return rc;
+    if (dx && (rc = linear_bwd_dx(dy, lddy, weight, dx, lddx, rows, n_out, n_in, 0, st))) return rc;
+    return 0;
+}
+extern "C" int tcvn_rows_bn_prelu_backward(const float* x, int64_t ldx, const float* dy, int64_t lddy, int rows, int channels,
+                                           const float* gamma, const float* beta, const float* slope, const float* save_mean_rstd,
+                                           float* dx, int64_t lddx, float* dgamma, float* dbeta, float* dslope, float drop_p,
+                                           uint64_t seed, uint32_t stream_id, void* stream) {
+    if (!x || !dy || !gamma || !beta || !slope || !save_mean_rstd || !dx || !dgamma || !dbeta || !dslope || rows <= 0 || channels <= 0) return -1;
+    RowsBnBwdArgs r{};
+    r.X = x; r.ldx = ldx; r.dY = dy; r.lddy = lddy; r.R = rows; r.C = channels; r.gamma = gamma; r.beta = beta; r.slope = slope;
+    r.save_mean = save_mean_rstd; r.save_rstd = save_mean_rstd + channels; r.dX = dx; r.lddx = lddx;
+    r.dgamma = dgamma; r.dbeta = dbeta; r.dslope = dslope; r.drop_p = drop_p; r.seed = seed; r.stream_id = stream_id;
+    return rows_bn_bwd(r, reinterpret_cast<hipStream_t>(stream));
 }
 
 // Stand-alone softmax focal loss of one logit matrix (reference: NeutrinoFullBaseTrainer.loss, :148-160)

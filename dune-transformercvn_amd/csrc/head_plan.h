@@ -12,7 +12,8 @@ namespace tcvn {
 struct HBn { int w, b, rm, rv; };
 struct HLayer { int win, bin, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2; };
 struct HDec { int w, b, a, in, out; HBn n; };
-struct HLayBuf { long qkv, probs, ctx, ao, xh1, rstd1, x1, hpre, hact, f, xh2, rstd2, g_dqkv, g_dao, g_dhp, g_df; };
+struct HLayBuf { long qkv, probs, ctx, ao, xh1, rstd1, x1, hpre, hact, f, xh2, rstd2, g_dqkv, g_dao, g_dhp, g_df,
+                 h1, h2; };     // h1 / h2: LayerNorm outputs of the pre-norm variant (transformer_norm_first)
 struct HLayout {
     long Zc, C, cstat, HID, LG, dEv, dPr, lossbuf, dLG, t0, t1, t2, t3, dHID, dC, dZc, lnp, total;
     std::vector<long> X, Zd, Ad, dstat;

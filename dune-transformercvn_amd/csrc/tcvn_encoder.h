@@ -35,6 +35,8 @@ int add_ln_bwd(const AddLnBwdArgs& a, hipStream_t st);
 int act_fwd(const float* X, float* Y, long n, int gelu, float drop_p, uint64_t seed, uint32_t sid, hipStream_t st);
 int act_bwd(const float* X, const float* dY, float* dX, long n, int gelu, float drop_p, uint64_t seed, uint32_t sid, hipStream_t st);
 int add_inplace(float* dst, const float* src, long n, hipStream_t st);
+int add_drop(const float* x, const float* r, float* y, long n, float drop_p, uint64_t seed, uint32_t sid, hipStream_t st);   // y = x + drop(r)
+int mul_drop(const float* dy, float* dr, long n, float drop_p, uint64_t seed, uint32_t sid, hipStream_t st);                  // dr = drop * dy
 
 // Fused encoder forward (encoder_fused.hip): all layers in one launch, one workgroup per event.  Weight / buffer pointers per layer.
 constexpr int ENC_MAX_LAYERS = 8;

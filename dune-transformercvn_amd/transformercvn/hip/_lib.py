@@ -87,6 +87,8 @@ def _load():
     sig("tcvn_head_decode", i32, vp, i32, i32, vp, vp, vp, vp, i64, i32, u64, vp)
     sig("tcvn_linear_forward", i32, vp, i64, vp, vp, vp, i64, i32, i32, i32, vp)
     sig("tcvn_rows_bn_prelu_forward", i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp, i32, f32, u64, C.c_uint32, vp)
+    sig("tcvn_linear_backward", i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, vp)
+    sig("tcvn_rows_bn_prelu_backward", i32, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, f32, u64, C.c_uint32, vp)
     sig("tcvn_focal_loss", i32, vp, vp, i32, i32, f32, f32, vp, vp, vp)
     sig("tcvn_grad_sumsq", i32, vp, i64, vp, i32, vp, vp)
     sig("tcvn_adamw_step", i32, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, vp, f32, vp)
@@ -114,7 +116,7 @@ def profile_records():
 EXPORTS = [
     "tcvn_grad_sumsq", "tcvn_adamw_step", "tcvn_backward_overlap", "tcvn_profile_enable", "tcvn_profile_filter", "tcvn_profile_reset", "tcvn_profile_count", "tcvn_profile_get",
     "tcvn_focal_loss", "tcvn_dropout_keep", "tcvn_head_set_fused_encoder", "tcvn_head_embed", "tcvn_head_encode", "tcvn_head_decode", "tcvn_linear_forward",
-    "tcvn_rows_bn_prelu_forward", "tcvn_sdxl_create", "tcvn_sdxl_destroy", "tcvn_sdxl_num_slots", "tcvn_sdxl_slot", "tcvn_sdxl_bind",
+    "tcvn_rows_bn_prelu_forward", "tcvn_linear_backward", "tcvn_rows_bn_prelu_backward", "tcvn_sdxl_create", "tcvn_sdxl_destroy", "tcvn_sdxl_num_slots", "tcvn_sdxl_slot", "tcvn_sdxl_bind",
     "tcvn_sdxl_workspace_bytes", "tcvn_sdxl_forward", "tcvn_sdxl_backward", "tcvn_sdxl_tap",
     "tcvn_version", "tcvn_densenet_create", "tcvn_densenet_destroy", "tcvn_densenet_num_slots", "tcvn_densenet_slot",
     "tcvn_densenet_bind", "tcvn_densenet_workspace_bytes", "tcvn_densenet_forward", "tcvn_densenet_backward",

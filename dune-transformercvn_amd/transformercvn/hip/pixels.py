@@ -6,7 +6,7 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor
 
-VALUE_RAW_255, VALUE_LOG, VALUE_READY = 0, 1, 2     # how the scatter kernel turns `values` into pixel intensities
+VALUE_RAW_255, VALUE_LOG, VALUE_READY, VALUE_ONE_HOT = 0, 1, 2, 3     # how the scatter kernel turns `values` into pixel intensities
 
 
 class SparsePixels:
@@ -42,6 +42,12 @@ class SparsePixels:
     def to_dense(self) -> Tensor:
         n = self.resolve_count()
         c = self.coords.long()
+        if self.value_mode == VALUE_ONE_HOT:                 # reference :47-52: 256-way one-hot per value channel
+            f = self.values.shape[1]
+            hot = torch.nn.functional.one_hot(self.values.long().clamp(0, 255), 256).reshape(-1, 256 * f).to(self.values.dtype)
+            out = torch.zeros(n, *self.shape, 256 * f, dtype=self.values.dtype, device=self.values.device)
+            out[c[:, 0], c[:, 1], c[:, 2]] = hot
+            return out.permute(0, 3, 1, 2).contiguous()
         out = torch.zeros(n, *self.shape, self.values.shape[1], dtype=self.values.dtype, device=self.values.device)
         out[c[:, 0], c[:, 1], c[:, 2]] = self.preprocessed_values()
         return out.permute(0, 3, 1, 2).contiguous()

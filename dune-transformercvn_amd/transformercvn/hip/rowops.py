@@ -50,3 +50,54 @@ def bn_prelu(x: Tensor, norm: nn.BatchNorm1d, slope: Tensor, training: bool, dro
     if training:
         norm.num_batches_tracked += 1
     return y
+
+
+class FeatureMLP:
+    """Forward / backward of ``ProngFeatureEmbedding.embedding`` (a chain of LinearBlocks: Linear(no bias) - BatchNorm1d - PReLU -
+    Dropout, reference layers/prong_feature_embedding.py:36-78) on the HIP row kernels, inside the fused training step: the
+    forward keeps what the backward needs, the backward accumulates parameter gradients into the runtime's gradient arena views."""
+
+    def __init__(self, blocks):
+        self.blocks = list(blocks)
+        self.saved = []
+
+    def forward(self, x: Tensor, training: bool, seed: int) -> Tensor:
+        self.saved = []
+        for i, blk in enumerate(self.blocks):
+            x = x.detach().float().contiguous()
+            z = linear(x, blk.linear.weight, blk.linear.bias)
+            rows, ch = z.shape
+            y = torch.empty_like(z)
+            stat = torch.empty(2 * ch, device=z.device)
+            p = float(blk.dropout.p) if training else 0.0
+            check(lib.tcvn_rows_bn_prelu_forward(C.c_void_p(z.data_ptr()), z.stride(0), rows, ch, C.c_void_p(blk.norm.weight.data_ptr()),
+                                                 C.c_void_p(blk.norm.bias.data_ptr()), C.c_void_p(blk.activation.weight.data_ptr()),
+                                                 C.c_void_p(blk.norm.running_mean.data_ptr()), C.c_void_p(blk.norm.running_var.data_ptr()),
+                                                 C.c_void_p(y.data_ptr()), y.stride(0), C.c_void_p(stat.data_ptr()), int(training), p,
+                                                 C.c_uint64(seed), C.c_uint32(0x4800 + i), _st()), "rows_bn_prelu_forward")
+            if training:
+                blk.norm.num_batches_tracked += 1
+            self.saved.append((x, z, stat, p, seed, 0x4800 + i))
+            x = y
+        return x
+
+    def backward(self, dy: Tensor, grads) -> None:
+        """grads: module parameter -> gradient tensor (views of the arena) to accumulate into."""
+        dy = dy.contiguous()
+        for blk, (x, z, stat, p, seed, sid) in zip(reversed(self.blocks), reversed(self.saved)):
+            rows, ch = z.shape
+            dz = torch.empty_like(z)
+            check(lib.tcvn_rows_bn_prelu_backward(C.c_void_p(z.data_ptr()), z.stride(0), C.c_void_p(dy.data_ptr()), dy.stride(0), rows, ch,
+                                                  C.c_void_p(blk.norm.weight.data_ptr()), C.c_void_p(blk.norm.bias.data_ptr()),
+                                                  C.c_void_p(blk.activation.weight.data_ptr()), C.c_void_p(stat.data_ptr()),
+                                                  C.c_void_p(dz.data_ptr()), dz.stride(0), C.c_void_p(grads[blk.norm.weight].data_ptr()),
+                                                  C.c_void_p(grads[blk.norm.bias].data_ptr()), C.c_void_p(grads[blk.activation.weight].data_ptr()),
+                                                  float(p), C.c_uint64(seed), C.c_uint32(sid), _st()), "rows_bn_prelu_backward")
+            dx = torch.empty_like(x)
+            gb = grads.get(blk.linear.bias) if blk.linear.bias is not None else None
+            check(lib.tcvn_linear_backward(C.c_void_p(dz.data_ptr()), dz.stride(0), C.c_void_p(x.data_ptr()), x.stride(0),
+                                           C.c_void_p(blk.linear.weight.data_ptr()), C.c_void_p(dx.data_ptr()), dx.stride(0),
+                                           C.c_void_p(grads[blk.linear.weight].data_ptr()), C.c_void_p(0 if gb is None else gb.data_ptr()),
+                                           rows, blk.linear.weight.shape[0], blk.linear.weight.shape[1], _st()), "linear_backward")
+            dy = dx
+        self.saved = []

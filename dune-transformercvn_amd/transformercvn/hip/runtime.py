@@ -63,10 +63,8 @@ class HipRuntime:
         pe = network.prong_embedding
         if not (options.linear_batch_norm and options.linear_prelu_activation):
             raise NotImplementedError("the MI355X path implements LinearBlock as Linear-BatchNorm1d-PReLU (both option files)")
-        if options.one_hot_pixels:
-            raise NotImplementedError("one_hot_pixels is not on the MI355X hot path (false in both option files)")
-        if not options.disable_smart_features:
-            raise NotImplementedError("smart prong features are not on the MI355X hot path (disabled in both option files)")
+        self.smart_features = not bool(options.disable_smart_features)     # a8: ProngFeatureEmbedding MLP on the row kernels
+        self.feature_mlp = None
         H, W = self.pixel_shape
         self.ev_engine = pe.event_pixel_embedding.hip_engine(self.mode, H, W)
         self.pr_engine = pe.prong_pixel_embedding.hip_engine(self.mode, H, W)
@@ -134,6 +132,7 @@ class HipRuntime:
         ps = [p for _, p in params]
         self._sig = (ps[0].data_ptr(), ps[-1].data_ptr())
         self._params = ps
+        self._param_grads = {p: g for p, g in zip(ps, self._grad_views)}       # parameter object -> its gradient view in the arena
         # gradient segments for overlapped all-reduce: parameters are laid out in registration order
         def span(prefix):
             keys = [k for k in offsets if k.startswith(prefix)]
@@ -175,6 +174,12 @@ class HipRuntime:
                                            dtype=torch.int64, device=dev)
         for i, m in enumerate(all_bn):
             m.num_batches_tracked.data = self.flat_nbt[i]
+
+    def _mlp(self):
+        if self.feature_mlp is None:
+            from .rowops import FeatureMLP
+            self.feature_mlp = FeatureMLP(self.network.prong_embedding.feature_embedding.embedding)
+        return self.feature_mlp
 
     def zero_grad(self):
         """Zero the gradient arena in one memset and (re)attach the per-parameter views."""
@@ -219,6 +224,10 @@ class HipRuntime:
         with torch.no_grad():
             rows = torch.zeros(B + n_prongs, in_dim, device=dev)
             rows[:, feat + pix:] = self._pos            # prongs also get the *event* position embedding (reference quirk)
+            if self.smart_features:                     # layers/prong_feature_embedding.py:73-78: MLP over [features | extra[event]]
+                i1, i2 = prong_mask.nonzero(as_tuple=True)
+                fin = torch.cat((features.to(dev)[i1, i2], extra.to(dev)[i1]), dim=1)
+                rows[B:, :feat] = self._mlp().forward(fin, training, seed ^ 0x4444)
             # the two embedders are independent until the token path: the small event DenseNet (B images) runs on a side
             # stream underneath the prong DenseNet (n_prongs images), whose launches alone do not fill the chip in the deep blocks
             main = torch.cuda.current_stream(dev)
@@ -269,6 +278,11 @@ class HipRuntime:
             seed = (self.seed * 1000003 + self.step) & 0x7FFFFFFFFFFFFFFF
             self.step += 1
             rows = self._rows(event_px, prong_px, B, n_prongs, training, seed)
+            if self.smart_features:
+                pe = self.network.prong_embedding
+                i1, i2 = prong_mask.nonzero(as_tuple=True)
+                fin = torch.cat((features.to(dev)[i1, i2], extra.to(dev)[i1]), dim=1)
+                rows[B:, :pe.feature_embedding_dim] = self._mlp().forward(fin, training, seed ^ 0x4444)
             if training:
                 self.flat_nbt += self._nbt_inc_embed
             return self.head.embed(rows, token_rows(prong_mask, B), B, P, n_prongs, training, seed ^ 0x3333)
@@ -293,6 +307,8 @@ class HipRuntime:
         hook = self.grad_ready_hook or (lambda tag: None)
         d_rows = self.head.backward(st["rows"], st["tok_row"], d_ev.contiguous(), d_pr.contiguous())
         self._pos_grad.add_(d_rows[:, feat + pix:].sum(0, keepdim=True))
+        if self.smart_features:
+            self._mlp().backward(d_rows[B:, :feat], self._param_grads)
         hook("head")
         if not d_rows.is_cuda:                       # CPU stand-ins (tests of the exchange schedule): one queue
             self.ev_engine.backward(d_rows[:B, :feat + pix])

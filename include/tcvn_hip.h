@@ -67,6 +67,8 @@ int64_t tcvn_densenet_workspace_bytes(const tcvn_densenet* p, int n_img, int wit
 int tcvn_densenet_forward(tcvn_densenet* p, int n_img, const int32_t* coords, const float* values, int64_t nnz,
                           int log_pixels, float noise_std, float* out, int64_t out_ld, void* workspace,
                           int64_t workspace_bytes, int train, uint64_t seed, void* stream);
+/* log_pixels: 0 = v/255, 1 = log(v+1), 2 = values are final, 3 = one_hot_pixels (reference :47-52): values [nnz, in_ch/256] hold
+ * integers 0..255, pixel channel f*256 + v is set to 1 (no scaling, no noise); conv0 then has in_ch = 256 * value channels. */
 
 /* Backward of the last train-mode forward on the same workspace: d_out [n_img, out_dim] fp32 -> parameter gradients
  * are ACCUMULATED into the bound grad pointers (zero them first). */
@@ -174,6 +176,15 @@ int tcvn_linear_forward(const float* x, int64_t ldx, const float* weight, const 
 int tcvn_rows_bn_prelu_forward(const float* x, int64_t ldx, int rows, int channels, const float* gamma, const float* beta,
                                const float* slope, float* running_mean, float* running_var, float* y, int64_t ldy,
                                float* save_mean_rstd, int train, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);
+
+/* Backward of the two row operators (used by the smart-feature MLP, layers/prong_feature_embedding.py:36-78, the only LinearBlocks
+ * outside the head plan): dx = dy W (NULL to skip), dweight += dy^T x, dbias += colsum(dy) (either may be NULL);
+ * BatchNorm1d(train statistics kept in save_mean_rstd by the forward) + PReLU + dropout backward, parameter gradients accumulated. */
+int tcvn_linear_backward(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* weight, float* dx, int64_t lddx,
+                         float* dweight, float* dbias, int rows, int n_out, int n_in, void* stream);
+int tcvn_rows_bn_prelu_backward(const float* x, int64_t ldx, const float* dy, int64_t lddy, int rows, int channels, const float* gamma,
+                                const float* beta, const float* slope, const float* save_mean_rstd, float* dx, int64_t lddx,
+                                float* dgamma, float* dbeta, float* dslope, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);
 
 /* Softmax focal loss and its gradient w.r.t. the logits (trainers/neutrino_full_base_trainer.py:148-177):
  * event_targets [batch] int64, prong_targets [batch, max_prongs] int8 (-1 = padding).

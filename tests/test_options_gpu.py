@@ -1,0 +1,72 @@
+"""The option branches both shipped option files leave off: smart prong features
+(layers/prong_feature_embedding.py:36-78), transformer_norm_first (layers/prong_custom_bert_encoder.py:45-52) and one_hot_pixels
+(trainers/neutrino_full_dense_trainer.py:47-52), each as a full fp32 train step against the CPU oracle."""
+import pytest
+import torch
+
+from oracle import tcvn_oracle as O
+from golden_utils import rel_err
+from model_utils import build_trainer, to_device
+from test_oracle_golden import is_noise_grad
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(densenet_structure=[2, 2], densenet_growth_rate=8, initial_pixel_dim=16, num_encoder_layers=2, pixel_embedding_dim=64,
+             hidden_dim=64, num_prong_decoder_layers=3, dropout=0.0, pixel_noise_std=0.0)
+
+
+def _step_vs_oracle(cfg, batch, tol=2e-3):
+    sd = O.fill_state(cfg, 21)
+    (total, el, pl), (ev, pr), grads, _ = O.train_step(sd, cfg, batch)
+    model = build_trainer(cfg, sd)
+    model.train()
+    model.network.hip_runtime().zero_grad()
+    dbatch = to_device(batch)
+    loss = model.training_step(dbatch, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - total.item()) < 1e-4 * abs(total.item()), (loss.item(), total.item())
+    named = dict(model.named_parameters())
+    worst, seen = 0.0, 0
+    for k, r in grads.items():
+        if is_noise_grad(k) or r.abs().max() < 1e-6 or k.endswith("event_position_embedding"):
+            continue
+        g = named[k].grad
+        assert g is not None, k
+        e = ((g.cpu() - r).norm() / r.norm()).item()
+        worst = max(worst, e)
+        seen += 1
+        assert e < tol, (k, e)
+    with torch.no_grad():
+        _, _, ev_g, pr_g = model.shared_step(dbatch)
+    assert rel_err(ev_g.cpu(), ev) < 1e-3 and rel_err(pr_g.cpu(), pr) < 1e-3
+    return worst, seen, grads, named
+
+
+def _with_features(batch, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    b = list(batch)
+    b[0] = torch.randn(b[0].shape, generator=g)
+    b[1] = torch.randn(b[1].shape, generator=g)
+    return tuple(b)
+
+
+def test_smart_prong_features_train_step():
+    cfg = O.tutorial_config(**dict(SMALL, disable_smart_features=False))
+    batch = _with_features(O.synthetic_batch([2, 3, 1], 31, cfg))
+    worst, seen, grads, named = _step_vs_oracle(cfg, batch)
+    k = "network.prong_embedding.feature_embedding.embedding.0.linear.weight"
+    assert grads[k].abs().max() > 1e-6 and named[k].grad.abs().max() > 1e-6          # the MLP really trains
+    print("smart features: worst rel L2 gradient error", worst, "over", seen, "tensors")
+
+
+def test_transformer_norm_first_train_step():
+    cfg = O.tutorial_config(**dict(SMALL, transformer_norm_first=True, dropout=0.0))
+    worst, seen, _, _ = _step_vs_oracle(cfg, O.synthetic_batch([2, 4, 1], 33, cfg))
+    print("norm_first: worst rel L2 gradient error", worst, "over", seen, "tensors")
+
+
+def test_one_hot_pixels_train_step():
+    cfg = O.tutorial_config(**dict(SMALL, one_hot_pixels=True))
+    worst, seen, _, _ = _step_vs_oracle(cfg, O.synthetic_batch([1, 2], 35, cfg, event_hits=(200, 400), prong_hits=(20, 100)))
+    print("one_hot_pixels: worst rel L2 gradient error", worst, "over", seen, "tensors")

@@ -83,3 +83,21 @@ def test_fp64_oracle_bounds_reference_noise():
     assert rel_err(g["train_prong_logits"], pr) < 2e-5
     for k in [k for k in g if k.startswith("grad:")]:
         assert grad_close(k[5:], g[k], grads[k[5:]].numpy(), rtol=3e-3), k
+
+
+def test_oracle_norm_first_layer_matches_torch_module():
+    """Pins the oracle's transformer_norm_first branch (no golden covers it: both option files use post-norm) to
+    torch.nn.TransformerEncoderLayer(norm_first=True), the module the reference instantiates (prong_custom_bert_encoder.py:45-52)."""
+    import torch
+    from torch import nn
+    cfg = O.tutorial_config(transformer_norm_first=True, hidden_dim=64, num_attention_heads=8)
+    layer = nn.TransformerEncoderLayer(64, 8, 64, 0.0, "gelu", norm_first=True).eval()
+    p = "network.encoder.encoder.layers.0"
+    sd = {f"{p}.{k}": v.detach() for k, v in layer.state_dict().items()}
+    x = torch.randn(5, 3, 64)
+    pad = torch.tensor([[False, False, True, True, True], [False] * 5, [False, False, False, True, True]])
+    with torch.no_grad():
+        ref = layer(x, src_key_padding_mask=pad)
+        mine = O.encoder_layer_forward(sd, p, cfg, x, pad, O._Ctx(False, 0.0))
+    valid = (~pad).t().unsqueeze(-1)
+    assert torch.allclose(mine * valid, ref * valid, atol=2e-6)
