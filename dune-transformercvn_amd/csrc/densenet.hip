@@ -585,6 +585,12 @@ int tcvn_densenet_backward(tcvn_densenet* p, int n_img, const float* d_out, int6
                            void* stream) {
     return p->plan.backward(n_img, d_out, d_out_ld, reinterpret_cast<char*>(ws), ws_bytes, reinterpret_cast<hipStream_t>(stream));
 }
+int tcvn_densenet_num_blocks(const tcvn_densenet* p) { return (int)p->plan.blocks.size(); }
+int tcvn_densenet_backward_blocks(tcvn_densenet* p, int n_img, const float* d_out, int64_t d_out_ld, void* ws, int64_t ws_bytes,
+                                  int block_hi, int block_lo, void* stream) {
+    return p->plan.backward(n_img, d_out, d_out_ld, reinterpret_cast<char*>(ws), ws_bytes, reinterpret_cast<hipStream_t>(stream), block_hi,
+                            block_lo);
+}
 int tcvn_densenet_tap(const tcvn_densenet* p, int n_img, const char* name, int64_t* byte_off, int* n, int* h, int* w, int* c,
                       int* ld, int* elem_bytes) {
     long off = 0;

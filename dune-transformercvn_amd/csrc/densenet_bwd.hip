@@ -59,8 +59,14 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     L.total = b.off;
 }
 
-int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, long ws_bytes, hipStream_t st) {
+// Blocks [bi_lo, bi_hi] of the backward pass (bi_hi == last block: also the output block; bi_lo == 0: also the stem).  A caller that
+// wants each block's parameter gradients as soon as they are final (data-parallel exchange overlapped with the rest of backward)
+// walks the blocks from the last to the first; one call with (n_blocks - 1, 0) is the whole backward.
+int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, long ws_bytes, hipStream_t st, int bi_hi, int bi_lo) {
     if (!bound) return -11;
+    if (bi_hi < 0) bi_hi = (int)blocks.size() - 1;
+    if (bi_lo < 0 || bi_lo > bi_hi || bi_hi >= (int)blocks.size()) return -1;
+    const bool first_part = bi_hi == (int)blocks.size() - 1, last_part = bi_lo == 0;
     if (n <= 0) return 0;
     if (n != last_n) { fprintf(stderr, "tcvn: densenet backward without matching forward\n"); return -13; }
     for (size_t i = 0; i < slots.size(); ++i)
@@ -108,20 +114,26 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
     // device table of unpack descriptors (depends on ws)
     if (undesc_ws != ws || undesc_total != L.total) {
         std::vector<UnpackDesc> ud;
+        unpack_first.assign(blocks.size() + 1, 0);            // descriptors are in wk_list order: conv0, then block by block
         for (size_t i = 0; i < wk_cache.size(); ++i) {
             const WkEntry& e = wk_cache[i];
             if (e.transpose || e.frag) continue;
+            for (size_t bi = 0; bi < blocks.size(); ++bi) {   // first descriptor of block bi = its first layer's conv1
+                if (!blocks[bi].layers.empty() && e.slot == blocks[bi].layers[0].w1) unpack_first[bi] = (int)ud.size();
+            }
             UnpackDesc d{reinterpret_cast<const float*>(ws + L.gwk + gw_off[i]), grad[e.slot], e.N, e.Cin, e.taps, e.Kp,
                          (fast3x3 && e.taps == 9) ? 1 : 0};
             ud.push_back(d);
         }
         n_unpack = (int)ud.size();
+        unpack_first[blocks.size()] = n_unpack;
         if (!d_undesc) TCVN_CHECK(hipMalloc(&d_undesc, ud.size() * sizeof(UnpackDesc)));
         h_undesc.assign(reinterpret_cast<char*>(ud.data()), reinterpret_cast<char*>(ud.data()) + ud.size() * sizeof(UnpackDesc));
         TCVN_CHECK(hipMemcpyAsync(d_undesc, h_undesc.data(), h_undesc.size(), hipMemcpyHostToDevice, st));
         undesc_ws = ws; undesc_total = L.total;
     }
 
+    if (first_part) {
     // Zeroed per backward: the (P, Q) tables and the kernel-layout weight gradients (one contiguous range behind the G buffers),
     // and those gradient buffers G[b] whose first contribution accumulates.  In the bf16 fast path the first writer of G[b] -- the
     // transition's pooled data gradient, or the head for the last block -- writes instead (g_write), which saves a 0.9 GB memset and
@@ -134,6 +146,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
         } else TCVN_CHECK(hipMemsetAsync(ws + L.G[bi], 0, (size_t)bytes, st));
     }
 
+    }
     auto bwd_link = [&](const BnSlots& s, int nblk, const double* bstat, long count, float* P, float* Q, int acc, int a_slot) -> int {
         BnBwdLinkArgs a{part, nblk, s.C, bstat, count, kEps, data[s.w], grad[s.w], grad[s.b], grad[a_slot], P, Q, acc};
         return bn_bwd_link(a, st);
@@ -145,7 +158,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
     float* dF = reinterpret_cast<float*>(ws + L.dF);
     float* dZ = reinterpret_cast<float*>(ws + L.dZ);
     float* hs = reinterpret_cast<float*>(ws + L.head_stat);
-    {
+    if (first_part) {
         RowsBnBwdArgs r{};
         r.X = Z; r.ldx = cfg.out_dim; r.dY = d_out; r.lddy = d_out_ld; r.R = n; r.C = cfg.out_dim;
         r.gamma = data[nl.w]; r.beta = data[nl.b]; r.slope = data[s_al]; r.save_mean = hs; r.save_rstd = hs + cfg.out_dim;
@@ -156,7 +169,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
         if ((rc = linear_bwd_dx(dZ, cfg.out_dim, data[s_wl], dF, Cf, n, cfg.out_dim, Cf, 0, st))) return rc;
     }
 
-    for (int bi = (int)blocks.size() - 1; bi >= 0; --bi) {
+    for (int bi = bi_hi; bi >= bi_lo; --bi) {
         const BlockGeom& bg = blocks[bi];
         const long M = (long)n * bg.H * bg.W;
         char* D = ws + L.D[bi];
@@ -314,7 +327,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
 
     // ---- stem: AvgPool0 - PReLU0 - BN0 - conv0 ----
     if ((rc = drain())) return rc;                // the stem weight gradient uses the slab; k_unpack reads every weight gradient
-    {
+    if (last_part) {
         const BlockGeom& b0 = blocks[0];
         float* P = reinterpret_cast<float*>(ws + L.pqD[0]);
         float* Q = P + b0.ld;
@@ -342,5 +355,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             if ((rc = stem_wgrad_sparse(sa, gw_of(s_w0), st))) return rc;
         } else if ((rc = conv_wgrad(w, st))) return rc;
     }
-    return unpack_wgrads(reinterpret_cast<const UnpackDesc*>(d_undesc), n_unpack, st);
+    // kernel-layout weight gradients of the blocks just finished -> reference OIHW gradients (conv0 rides with block 0)
+    const int u0 = last_part ? 0 : unpack_first[bi_lo], u1 = unpack_first[bi_hi + 1];
+    return unpack_wgrads(reinterpret_cast<const UnpackDesc*>(d_undesc) + u0, u1 - u0, st);
 }

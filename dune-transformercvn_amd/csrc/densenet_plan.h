@@ -74,7 +74,8 @@ struct DenseNetPlan {
     int upload_descs(char* ws, const Layout& L, hipStream_t st);
     int forward(int n, const int32_t* coords, const float* values, long nnz, int log_pixels, float noise_std, float* out,
                 long out_ld, char* ws, long ws_bytes, int train, uint64_t seed, hipStream_t st);
-    int backward(int n, const float* d_out, long d_out_ld, char* ws, long ws_bytes, hipStream_t st);
+    int backward(int n, const float* d_out, long d_out_ld, char* ws, long ws_bytes, hipStream_t st, int bi_hi = -1, int bi_lo = 0);
+    std::vector<int> unpack_first;   // first unpack descriptor of every block (+ total): partial backward calls unpack their own blocks
     int tap(int n, const char* name, long* off, int* tn, int* th, int* tw, int* tc, int* tld, int* tes) const;
 };
 

@@ -62,6 +62,8 @@ def _load():
     sig("tcvn_densenet_workspace_bytes", i64, vp, i32, i32)
     sig("tcvn_densenet_forward", i32, vp, i32, vp, vp, i64, i32, f32, vp, i64, vp, i64, i32, u64, vp)
     sig("tcvn_densenet_backward", i32, vp, i32, vp, i64, vp, i64, vp)
+    sig("tcvn_densenet_num_blocks", i32, vp)
+    sig("tcvn_densenet_backward_blocks", i32, vp, i32, vp, i64, vp, i64, i32, i32, vp)
     sig("tcvn_densenet_tap", i32, vp, i32, C.c_char_p, P(i64), P(i32), P(i32), P(i32), P(i32), P(i32), P(i32))
     sig("tcvn_sdxl_create", i32, P(SdxlCfg), P(vp))
     sig("tcvn_sdxl_destroy", None, vp)
@@ -120,7 +122,7 @@ EXPORTS = [
     "tcvn_sdxl_workspace_bytes", "tcvn_sdxl_forward", "tcvn_sdxl_backward", "tcvn_sdxl_tap",
     "tcvn_version", "tcvn_densenet_create", "tcvn_densenet_destroy", "tcvn_densenet_num_slots", "tcvn_densenet_slot",
     "tcvn_densenet_bind", "tcvn_densenet_workspace_bytes", "tcvn_densenet_forward", "tcvn_densenet_backward",
-    "tcvn_densenet_tap", "tcvn_head_create", "tcvn_head_destroy", "tcvn_head_num_slots", "tcvn_head_slot", "tcvn_head_bind",
+    "tcvn_densenet_tap", "tcvn_densenet_num_blocks", "tcvn_densenet_backward_blocks", "tcvn_head_create", "tcvn_head_destroy", "tcvn_head_num_slots", "tcvn_head_slot", "tcvn_head_bind",
     "tcvn_head_workspace_bytes", "tcvn_head_forward", "tcvn_head_loss", "tcvn_head_backward",
 ]
 

@@ -15,18 +15,20 @@ import torch.distributed as dist
 
 
 def segment_plan(total: int, spans: Dict[str, Tuple[int, int]]) -> Dict[str, List[Tuple[int, int]]]:
-    """Map each readiness tag to the [lo, hi) slices of the flat gradient it completes.  'head' owns everything that is
-    neither the event nor the prong embedder span."""
-    (plo, phi), (elo, ehi) = spans["prong"], spans["event"]
-    cuts = sorted([(plo, phi), (elo, ehi)])
+    """Map each readiness tag to the [lo, hi) slices of the flat gradient it completes.  Every entry of `spans` is a tag with its
+    own slice ("event", "prong", or "prong0" ... "prong4" when the prong embedder's backward is issued block by block);
+    'head' owns everything no span covers (token path, position embeddings, ...)."""
+    cuts = sorted(spans.values())
     head, pos = [], 0
     for lo, hi in cuts:
         if lo > pos:
             head.append((pos, lo))
-        pos = hi
+        pos = max(pos, hi)
     if pos < total:
         head.append((pos, total))
-    return {"head": head, "event": [(elo, ehi)], "prong": [(plo, phi)]}
+    plan = {tag: [span] for tag, span in spans.items()}
+    plan["head"] = head
+    return plan
 
 
 class GradReducer:

@@ -133,6 +133,23 @@ class DenseNetEngine(_EmbedderEngine):
         self.mode = mode
         self.out_dim = out_dim
         check(lib.tcvn_densenet_create(C.byref(cfg), C.byref(self.handle)), "densenet_create")
+        self.n_parts = lib.tcvn_densenet_num_blocks(self.handle)       # backward can be issued block by block (last block first)
+
+    def backward_part(self, d_out: torch.Tensor, part: int):
+        """Backward of dense block `part` alone (call with part = n_parts-1 ... 0): tcvn_densenet_backward_blocks."""
+        assert d_out.dtype == torch.float32 and d_out.stride(1) == 1 and d_out.shape == (self._n, self.out_dim)
+        ws = self._ws
+        check(lib.tcvn_densenet_backward_blocks(self.handle, self._n, _ptr(d_out), d_out.stride(0), _ptr(ws), ws.numel(), part, part,
+                                                _stream_ptr()), "densenet_backward_blocks")
+
+    def part_prefixes(self, part: int):
+        """Parameter-name prefixes (relative to the DenseNet module) whose gradients are final after backward_part(part)."""
+        pre = [f"features.dense{part + 1}.", f"features.transition{part + 1}."]
+        if part == self.n_parts - 1:
+            pre += ["features.final_norm.", "features.final_relu.", "output_block."]
+        if part == 0:
+            pre += ["features.conv0.", "features.norm0.", "features.relu0."]
+        return pre
 
 
 class SdxlEngine(_EmbedderEngine):

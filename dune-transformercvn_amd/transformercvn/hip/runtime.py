@@ -139,8 +139,17 @@ class HipRuntime:
             lo = min(offsets[k][0] for k in keys)
             hi = max(offsets[k][0] + offsets[k][1] for k in keys)
             return lo, hi
-        self.segments = {"prong": span("prong_embedding.prong_pixel_embedding."),
-                         "event": span("prong_embedding.event_pixel_embedding.")}
+        self.segments = {"event": span("prong_embedding.event_pixel_embedding.")}
+        pfx = "prong_embedding.prong_pixel_embedding."
+        parts = getattr(self.pr_engine, "n_parts", 0)
+        if parts > 1:      # the prong embedder's backward is issued block by block: one exchange segment per dense block
+            for part in range(parts):
+                keys = [k for k in offsets if any(k.startswith(pfx + q) for q in self.pr_engine.part_prefixes(part))]
+                self.segments[f"prong{part}"] = (min(offsets[k][0] for k in keys), max(offsets[k][0] + offsets[k][1] for k in keys))
+            covered = sum(hi - lo for t, (lo, hi) in self.segments.items() if t.startswith("prong"))
+            assert covered == span(pfx)[1] - span(pfx)[0], "prong embedder segments must tile its parameter span"
+        else:
+            self.segments["prong"] = span(pfx)
         # bind the native plans to the views
         named_p = dict(net.named_parameters())
         named_b = {n: b for n, b in net.named_buffers() if b.is_floating_point()}
@@ -322,8 +331,20 @@ class HipRuntime:
         with torch.cuda.stream(side):                # event embedder backward underneath the prong embedder's (see forward)
             self.ev_engine.backward(d_rows[:B, :feat + pix])
             hook("event")                            # issued from the side stream: the collective is ordered behind the event backward
-        self.pr_engine.backward(d_rows[B:, feat:feat + pix])
-        hook("prong")
+        d_pr_rows = d_rows[B:, feat:feat + pix]
+        parts = getattr(self.pr_engine, "n_parts", 0)
+        if self.grad_ready_hook is not None and parts > 1:
+            # data parallel: dense blocks 5 -> 1, each block's gradient slice goes to the exchange while the earlier blocks still run;
+            # only block 1 + stem (the last slice) is exposed
+            for part in range(parts - 1, -1, -1):
+                self.pr_engine.backward_part(d_pr_rows, part)
+                hook(f"prong{part}")
+        else:
+            self.pr_engine.backward(d_pr_rows)
+            for part in range(parts - 1, -1, -1) if parts > 1 else ():
+                hook(f"prong{part}")
+            if parts <= 1:
+                hook("prong")
         main.wait_stream(side)
 
     def loss(self, ev: Tensor, pr: Tensor, event_targets: Tensor, prong_targets: Tensor):

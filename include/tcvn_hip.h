@@ -75,6 +75,14 @@ int tcvn_densenet_forward(tcvn_densenet* p, int n_img, const int32_t* coords, co
 int tcvn_densenet_backward(tcvn_densenet* p, int n_img, const float* d_out, int64_t d_out_ld, void* workspace,
                            int64_t workspace_bytes, void* stream);
 
+/* The same backward in slices: dense blocks block_hi ... block_lo (0-based, walked downwards).  block_hi = n_blocks-1 also runs the
+ * output block, block_lo = 0 also the stem; the parameter gradients of a slice are final when its call returns (in stream order), so
+ * a data-parallel caller can start their all-reduce under the remaining slices.  Slices must be issued from the last block to the
+ * first and cover every block exactly once. */
+int tcvn_densenet_num_blocks(const tcvn_densenet* p);
+int tcvn_densenet_backward_blocks(tcvn_densenet* p, int n_img, const float* d_out, int64_t d_out_ld, void* workspace,
+                                  int64_t workspace_bytes, int block_hi, int block_lo, void* stream);
+
 /* Debug/validation taps into the workspace of the last forward: name in {"img","conv0","dense<b>","bottleneck<b>.<l>","condense"},
  * in bf16 mode also the materialised operands "xa<b>.<l>" / "ya<b>.<l>" and the raw regions "raw:wk","raw:tabs","raw:bstat<b>";
  * returns the byte offset into the workspace and the logical NHWC shape + channel stride + element size. */

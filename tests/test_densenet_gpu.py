@@ -309,3 +309,36 @@ def test_backward_side_stream_option_gives_the_same_gradients():
             worst = max(worst, (g0[k] - g1[k]).abs().max().item() / scale)
     print("serial vs side-stream backward: worst relative gradient difference", worst)
     assert worst < 1e-3
+
+
+def test_backward_in_block_slices_equals_whole_backward():
+    """tcvn_densenet_backward_blocks (data-parallel overlap: one slice per dense block, last block first) against the single call."""
+    cfg, over, batch, g = load_case("tutorial_b2p4")
+    cfg = train_cfg(over)
+    sd = O.fill_state(cfg, int(g["weight_seed"]))
+    n_img = int(batch[7].sum())
+    d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5)).cuda()
+    res = []
+    for sliced in (False, True):
+        eng, data, grads = _engine(cfg, sd, mode=1, with_grad=True)
+        out = torch.empty(n_img, eng.out_dim, device="cuda")
+        eng.forward(batch[5].cuda(), batch[6].cuda(), n_img, out, train=True, seed=3)
+        if sliced:
+            assert eng.n_parts == len(cfg.densenet_structure)
+            for part in range(eng.n_parts - 1, -1, -1):
+                eng.backward_part(d_out, part)
+        else:
+            eng.backward(d_out)
+        torch.cuda.synchronize()
+        res.append({k: v.clone() for k, v in grads.items()})
+    worst = 0.0
+    for k in res[0]:
+        scale = res[0][k].abs().max().item()
+        if scale > 0:
+            worst = max(worst, (res[0][k] - res[1][k]).abs().max().item() / scale)
+    print("sliced vs whole backward: worst relative gradient difference", worst)
+    assert worst < 1e-6
+    covered = set()
+    for part in range(eng.n_parts):
+        covered |= {k for k in res[0] if any(k.startswith(p) for p in eng.part_prefixes(part))}
+    assert covered == set(res[0])                      # the slices' name prefixes tile the parameter set

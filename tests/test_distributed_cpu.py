@@ -114,6 +114,30 @@ def _runtime_worker(rank, world, port, ret):
     ok = ok and torch.allclose(rt.flat_grad[lo:hi], mean_scale * torch.arange(hi - lo, dtype=torch.float32))
     lo, hi = rt.segments["prong"]
     ok = ok and torch.allclose(rt.flat_grad[lo:hi], mean_scale_pr * torch.arange(hi - lo, dtype=torch.float32))
+    # block-wise prong backward: one exchange segment per dense block, issued last block first
+    class _Parts:
+        n_parts = 2
+
+        def __init__(self, arena, spans, value):
+            self.arena, self.spans, self.value = arena, spans, value
+
+        def backward_part(self, d, part):
+            lo, hi = self.spans[part]
+            self.arena[lo:hi] += self.value * (part + 1)
+    plo, phi = rt.segments.pop("prong")
+    mid = (plo + phi) // 2
+    rt.segments["prong0"], rt.segments["prong1"] = (plo, mid), (mid, phi)
+    rt.flat_grad.zero_()
+    rt.pr_engine = _Parts(rt.flat_grad, [(plo, mid), (mid, phi)], float(rank + 1))
+    assert model.enable_data_parallel() is not None
+    order.clear()
+    inner2 = rt.grad_ready_hook
+    rt.grad_ready_hook = lambda tag: (order.append(tag), inner2(tag))
+    rt._backward(st, torch.zeros(2, 4), torch.zeros(2, 3, 8))
+    model.on_after_backward()
+    ok = ok and order == ["head", "event", "prong1", "prong0"]
+    ok = ok and torch.allclose(rt.flat_grad[plo:mid], torch.full((mid - plo,), mean_scale))
+    ok = ok and torch.allclose(rt.flat_grad[mid:phi], torch.full((phi - mid,), 2 * mean_scale))
     # torch DDP accepts the module: everything but the hidden anchor is on the ignore list, checkpoints keep the reference keys
     ddp = torch.nn.parallel.DistributedDataParallel(model)
     managed = [n for n, p in ddp.module.named_parameters() if n not in model._ddp_params_and_buffers_to_ignore]
