@@ -319,11 +319,11 @@ class HipRuntime:
         if self.smart_features:
             self._mlp().backward(d_rows[B:, :feat], self._param_grads)
         hook("head")
+        d_pr_rows = d_rows[B:, feat:feat + pix]
         if not d_rows.is_cuda:                       # CPU stand-ins (tests of the exchange schedule): one queue
             self.ev_engine.backward(d_rows[:B, :feat + pix])
             hook("event")
-            self.pr_engine.backward(d_rows[B:, feat:feat + pix])
-            hook("prong")
+            self._prong_backward(d_pr_rows, hook)
             return
         main = torch.cuda.current_stream(d_rows.device)
         side = self._side if self.overlap_embedders else main
@@ -331,21 +331,25 @@ class HipRuntime:
         with torch.cuda.stream(side):                # event embedder backward underneath the prong embedder's (see forward)
             self.ev_engine.backward(d_rows[:B, :feat + pix])
             hook("event")                            # issued from the side stream: the collective is ordered behind the event backward
-        d_pr_rows = d_rows[B:, feat:feat + pix]
+        self._prong_backward(d_pr_rows, hook)
+        main.wait_stream(side)
+
+    def _prong_backward(self, d_pr_rows: Tensor, hook):
+        """Prong embedder backward.  Data parallel (a hook is installed) and an engine that can be driven block by block: dense
+        blocks 5 -> 1, each block's gradient slice goes to the exchange while the earlier blocks still run, so only block 1 + stem
+        (the last slice) is exposed.  Otherwise one call."""
         parts = getattr(self.pr_engine, "n_parts", 0)
-        if self.grad_ready_hook is not None and parts > 1:
-            # data parallel: dense blocks 5 -> 1, each block's gradient slice goes to the exchange while the earlier blocks still run;
-            # only block 1 + stem (the last slice) is exposed
+        if parts > 1 and self.grad_ready_hook is not None:
             for part in range(parts - 1, -1, -1):
                 self.pr_engine.backward_part(d_pr_rows, part)
                 hook(f"prong{part}")
         else:
             self.pr_engine.backward(d_pr_rows)
-            for part in range(parts - 1, -1, -1) if parts > 1 else ():
-                hook(f"prong{part}")
-            if parts <= 1:
+            if parts > 1:
+                for part in range(parts - 1, -1, -1):
+                    hook(f"prong{part}")
+            else:
                 hook("prong")
-        main.wait_stream(side)
 
     def loss(self, ev: Tensor, pr: Tensor, event_targets: Tensor, prong_targets: Tensor):
         """-> (total, event_loss, prong_loss, event_accuracy, prong_accuracy) as 0-d device tensors; total is differentiable."""
