@@ -20,6 +20,11 @@ LABELS = {            # bench.py label -> substring of the demangled kernel name
     "k_conv3x3_wgrad_bf16": "k_conv3x3_wgrad_bf16",
     "k_stem_fwd_bf16": "k_stem_fwd_bf16",
     "k_act_bf16": "k_act_bf16",
+    "k_eff_mat": "k_eff_mat",
+    "k_gemm_tn_bf16<conv1>": "k_gemm_tn_bf16<0>",
+    "k_gemm_nt_bf16<fwd1x1>": "k_gemm_nt_bf16<0, ",
+    "k_encoder_fwd": "k_encoder_fwd",
+    "k_encoder_bwd": "k_encoder_bwd",
 }
 
 
@@ -41,9 +46,15 @@ def main():
         out[label] = {"launches": len(f), "fetch_bytes_per_launch": 2 * 1024 * sum(f) / len(f),
                       "write_bytes_per_launch": 1024 * sum(w) / len(w),
                       "traffic_bytes_per_launch": 2 * 1024 * sum(f) / len(f) + 1024 * sum(w) / len(w)}
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    if steps:          # whole run / steps: every kernel of the two passes (weights packing, token path, torch helpers included)
+        tf = 2 * 1024 * sum(v for vs in fetch.values() for v in vs) / steps
+        tw = 1024 * sum(v for vs in write.values() for v in vs) / steps
+        out["_whole_step"] = {"steps_in_run": steps, "fetch_bytes": tf, "write_bytes": tw, "traffic_bytes": tf + tw}
+        print(f"whole step: {tf / 1e9:.1f} GB read + {tw / 1e9:.1f} GB written = {(tf + tw) / 1e9:.1f} GB")
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print(f"{k:32s} {v['launches']:5d} launches  {v['traffic_bytes_per_launch'] / 1e6:9.1f} MB/launch")
 
 
