@@ -98,6 +98,7 @@ def sdxl_flops_per_image(init_ch=64, out_dim=256, H=400, W=280, in_ch=3):
 
 
 def make_batch(batch, prongs, seed, device):
+    """`prongs`: int (fixed) or (lo, hi) for ragged events"""
     from transformercvn.dataset.minkowski_dataset import SyntheticDataset, MinkowskiCollection
     ds = SyntheticDataset(batch, prongs, seed=seed)
     b = MinkowskiCollection()([ds[i] for i in range(batch)])
@@ -180,11 +181,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--sdxl", action="store_true", help="BASELINE config 4: the SDXL-style embedder (train.py --sdxl), batch 16")
+    ap.add_argument("--ragged-inference", action="store_true",
+                    help="BASELINE config 5: eval-mode forward only, 1..16 prongs per event (packed attention mask)")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--prongs", type=int, default=8)
     ap.add_argument("--dropout", type=float, default=None, help="override options.dropout (experiments only; the metric uses the file's 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--side-priority", type=int, default=None, help="A/B: priority of the event-embedder side stream (-1 = high)")
     ap.add_argument("--bwd-overlap", action="store_true", help="A/B: weight-gradient kernels on a side stream (tcvn_backward_overlap(1))")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing (fp32_ms_per_step)")
     ap.add_argument("--dump-records", default="", help="write every profiled launch (name, ms, flops) to this JSON file")
@@ -225,15 +229,22 @@ def main():
     model = NeutrinoFullDenseTrainer(opt).to(dev)
     model.train()
     rt = model.network.hip_runtime()
+    if args.side_priority is not None:
+        rt.side_priority = args.side_priority
     rt.ensure_bound()
     if args.bwd_overlap:
         _lib.lib.tcvn_backward_overlap(1)
-    batch = make_batch(args.batch, args.prongs, 1234 + rank, dev)
+    batch = make_batch(args.batch, (1, 16) if args.ragged_inference else args.prongs, 1234 + rank, dev)
+    if args.ragged_inference:
+        model.eval()
     reducer = GradReducer(rt.flat_grad, rt.segments) if world > 1 else None
     if reducer:
         rt.grad_ready_hook = reducer.on_ready
 
     def step():
+        if args.ragged_inference:                 # inference only: no loss, no backward, no exchange (embarrassingly parallel)
+            with torch.no_grad():
+                return model.shared_step(batch)[2].sum()
         if reducer:
             broadcast_buffers(rt.flat_buf)
         rt.zero_grad()
@@ -343,13 +354,22 @@ def main():
         if args.sdxl:        # per-image FLOPs of the two embedders differ only in the last stage (out 256 / 288): use the prong value
             flop_img = (args.prongs * sdxl_flops_per_image(out_dim=256)[1] + sdxl_flops_per_image(out_dim=288)[1]) / (1 + args.prongs)
         per_gpu_tflops = (args.batch * (1 + args.prongs) * flop_img) / (elapsed / args.steps) / 1e12
+        n_maps = args.batch * (1 + args.prongs)
+        if args.ragged_inference:                 # forward only over the actual number of maps of this batch
+            n_maps = args.batch + batch[10][1]
+            flop_img = 4.9706e9
+            per_gpu_tflops = n_maps * flop_img / (elapsed / args.steps) / 1e12
         out = {
-            "metric": "events/sec (fwd+bwd) at batch=32, 8 prongs/event; fraction of MFMA roofline" if not args.sdxl else
+            "metric": "events/sec (inference only) on ragged batches, 1-16 prongs/event, packed attention mask" if args.ragged_inference else
+                      "events/sec (fwd+bwd) at batch=32, 8 prongs/event; fraction of MFMA roofline" if not args.sdxl else
                       "events/sec (fwd+bwd) at batch=16, 8 prongs/event, --sdxl embedder; fraction of MFMA roofline",
             "value": round(value, 2), "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": (f"TransformerCVN DenseNet [3,6,12,6,3] g32, fwd+loss+bwd, batch {args.batch}/GPU, "
+            "config": {"workload": (f"TransformerCVN DenseNet [3,6,12,6,3] g32, eval-mode forward only, batch {args.batch}/GPU, ragged "
+                                    f"1-16 prongs/event ({n_maps - args.batch} prong maps in this batch), 3x400x280 maps, 6-layer encoder")
+                                   if args.ragged_inference else
+                                   (f"TransformerCVN DenseNet [3,6,12,6,3] g32, fwd+loss+bwd, batch {args.batch}/GPU, "
                                     f"{args.prongs} prongs/event, 3x400x280 maps, 6-layer encoder, dropout 0.1") if not args.sdxl else
                                    (f"TransformerCVN --sdxl embedder (VAE-encoder blocks [64,64,128,128,256,256,512,512,out], GroupNorm(1), "
                                     f"parity unpinned), fwd+loss+bwd, batch {args.batch}/GPU, {args.prongs} prongs/event, 3x400x280 maps"),
@@ -361,13 +381,13 @@ def main():
         if roof:
             out["roofline"] = roof
             out["kernels"] = kernels[:8]
-        if args.precision == "bf16" and world == 1 and not args.no_fp32 and not args.sdxl:
+        if args.precision == "bf16" and world == 1 and not args.no_fp32 and not args.sdxl and not args.ragged_inference:
             note("fp32 parity mode (1 warm-up + 2 steps) ...")
             del model, rt
             torch.cuda.empty_cache()
             out["fp32_ms_per_step"] = round(fp32_parity_mode_ms(opt_path, args, dev, batch), 2)
             out["fp32_events_per_s"] = round(args.batch / out["fp32_ms_per_step"] * 1000, 1)
-        if not args.no_cpu_baseline and world == 1 and not args.sdxl:       # rank 0 at N=1 only (DenseNet workload)
+        if not args.no_cpu_baseline and world == 1 and not args.sdxl and not args.ragged_inference:       # rank 0 at N=1 only (DenseNet workload)
             note("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline(host_threads(), args.prongs)
         print(json.dumps(out))

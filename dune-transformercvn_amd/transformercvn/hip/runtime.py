@@ -80,6 +80,7 @@ class HipRuntime:
         self._sig = None
         self._grad_views: List[Tensor] = []
         self.overlap_embedders = True        # event DenseNet on a side stream underneath the prong DenseNet
+        self.side_priority = 0               # stream priority of that side stream (0 = default, -1 = high)
         self.anchor_param = None             # optional: module-owned anchor parameter (see NeutrinoFullBaseTrainer)
         self.grad_ready_hook = None          # called as hook(tag) when a gradient segment is final ("head", "event", "prong")
         self.segments: Dict[str, Tuple[int, int]] = {}
@@ -174,7 +175,7 @@ class HipRuntime:
                for m in mod.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
         # num_batches_tracked of every BatchNorm become views of one int64 arena: one add per step instead of 139
         all_bn = [m for m in net.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d))]
-        self._side = torch.cuda.Stream(dev)          # event-embedder stream (forward/_backward)
+        self._side = torch.cuda.Stream(dev, priority=self.side_priority)     # event-embedder stream (forward/_backward)
         self.flat_nbt = torch.stack([m.num_batches_tracked.to(dev) for m in all_bn]).contiguous()
         ran_ids = {id(m) for m in ran}
         self._nbt_inc = torch.tensor([1 if id(m) in ran_ids else 0 for m in all_bn], dtype=torch.int64, device=dev)
