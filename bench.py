@@ -189,7 +189,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--side-priority", type=int, default=None, help="A/B: priority of the event-embedder side stream (-1 = high)")
-    ap.add_argument("--bwd-overlap", action="store_true", help="A/B: weight-gradient kernels on a side stream (tcvn_backward_overlap(1))")
+    ap.add_argument("--no-bwd-overlap", action="store_true", help="A/B: keep the weight-gradient kernels on the main stream (tcvn_backward_overlap(0))")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing (fp32_ms_per_step)")
     ap.add_argument("--dump-records", default="", help="write every profiled launch (name, ms, flops) to this JSON file")
     args = ap.parse_args()
@@ -232,8 +232,8 @@ def main():
     if args.side_priority is not None:
         rt.side_priority = args.side_priority
     rt.ensure_bound()
-    if args.bwd_overlap:
-        _lib.lib.tcvn_backward_overlap(1)
+    if args.no_bwd_overlap:
+        _lib.lib.tcvn_backward_overlap(0)
     batch = make_batch(args.batch, (1, 16) if args.ragged_inference else args.prongs, 1234 + rank, dev)
     if args.ragged_inference:
         model.eval()
@@ -266,6 +266,7 @@ def main():
     profiled = rank == 0 and not args.no_profile
     if not args.no_profile:
         rt.overlap_embedders = False
+        _lib.lib.tcvn_backward_overlap(0)          # serial per-kernel timings for the survey
         if profiled:
             _lib.lib.tcvn_profile_filter(None)
             _lib.lib.tcvn_profile_reset()
@@ -273,6 +274,7 @@ def main():
         step()
         torch.cuda.synchronize()
         rt.overlap_embedders = True
+        _lib.lib.tcvn_backward_overlap(0 if args.no_bwd_overlap else 1)
         if profiled:
             _lib.lib.tcvn_profile_enable(0)
             records = _lib.profile_records()

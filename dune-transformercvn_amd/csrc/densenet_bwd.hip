@@ -11,10 +11,10 @@
 
 using namespace tcvn;
 
-// tcvn_backward_overlap(): off by default.  Measured on MI355X (B=32 x 8 prongs, 3 alternating runs each): 27.16 ms with the
-// weight gradients on the side stream vs 27.43 ms without (1 %); the overlapped kernels then share the CUs, which doubles the
-// per-launch times a profiler sees for them -- not worth it while kernels are still being tuned one by one.
-static int g_backward_overlap = 0;
+// tcvn_backward_overlap(): ON by default since round 2.  Measured on MI355X (B=32 x 8 prongs, alternating runs): 26.0-26.1 ms with the
+// weight gradients on the side stream vs 26.4 ms without (-1.2 %).  The overlapped kernels share the CUs, which inflates the
+// per-launch times an event pair sees for them: bench.py's survey step (the per-kernel roofline leg) switches it off while it measures.
+static int g_backward_overlap = 1;
 bool tcvn::backward_overlap_enabled() { return g_backward_overlap != 0; }
 void tcvn::set_backward_overlap(int on) { g_backward_overlap = on; }
 

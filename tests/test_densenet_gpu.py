@@ -295,12 +295,12 @@ def test_backward_side_stream_option_gives_the_same_gradients():
     sd = O.fill_state(cfg, int(g["weight_seed"]))
     n_img = int(batch[7].sum())
     d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
-    out0, _, g0 = _run_bf16(cfg, sd, batch, True, d_out)
-    lib.tcvn_backward_overlap(1)
+    lib.tcvn_backward_overlap(0)
     try:
-        out1, _, g1 = _run_bf16(cfg, sd, batch, True, d_out)
+        out0, _, g0 = _run_bf16(cfg, sd, batch, True, d_out)
     finally:
-        lib.tcvn_backward_overlap(0)
+        lib.tcvn_backward_overlap(1)                      # the default
+    out1, _, g1 = _run_bf16(cfg, sd, batch, True, d_out)
     assert torch.equal(out0, out1)
     worst = 0.0
     for k in g0:
