@@ -213,18 +213,7 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(const ConvWgradArgs g, int ro
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave / WJ, wj = wave % WJ;
-    // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so consecutive ids -- by default the
-    // j-tiles (for a 3x3 convolution: the 9 taps) of ONE pixel chunk -- land on 8 different L2s and every tap's shifted re-read
-    // of the same input rows misses.  Give all j-tiles of pixel chunk z to XCD z % 8 instead: id = x + gx * z  ->  xcd = id % 8,
-    // q = id / 8, chunk = xcd + 8 * (q / gx), j-tile = q % gx.  Needs gridDim.z % 8 == 0 (launcher) -- otherwise the identity map.
-    int bx = blockIdx.x, bz = blockIdx.z;
-    if ((gridDim.z & 7) == 0 && gridDim.x > 1) {
-        const int id = blockIdx.x + gridDim.x * blockIdx.z;
-        const int xcd = id & 7, qq = id >> 3;
-        bz = xcd + 8 * (qq / (int)gridDim.x);
-        bx = qq % (int)gridDim.x;
-    }
-    const int j0 = bx * BJ, i0 = blockIdx.y * BI;
+    const int j0 = blockIdx.x * BJ, i0 = blockIdx.y * BI;
     const ConvFwdArgs& fa = g.fa;
     const EffSrc& e = g.e;
     const T* __restrict__ A = reinterpret_cast<const T*>(fa.A);
@@ -234,9 +223,9 @@ __global__ __launch_bounds__(NT) void k_conv_wgrad(const ConvWgradArgs g, int ro
     const bool avec = ((fa.lda & 7) == 0) && ((reinterpret_cast<uintptr_t>(A) & ALIGN) == 0) &&
                       (AMODE == A_3X3 ? (fa.C & 7) == 0 : (fa.K & 7) == 0) && AMODE != A_STEM;
     const bool evec = eff_vec<T>(e);
-    const int m_begin = bz * rows_per_split;
+    const int m_begin = blockIdx.z * rows_per_split;
     const int m_end = min(fa.M, m_begin + rows_per_split);
-    const bool do_bias = g.dbias != nullptr && bx == 0;
+    const bool do_bias = g.dbias != nullptr && blockIdx.x == 0;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -365,13 +354,8 @@ int launch_wgrad(const ConvWgradArgs& a, hipStream_t st) {
     const int max_split = cdiv(M, 512);
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
-    int rows = (int)round_up(cdiv(M, split), BK);
+    const int rows = (int)round_up(cdiv(M, split), BK);
     split = cdiv(M, rows);
-    if (split >= 16 && it == 1) {               // multiple of 8 pixel chunks: enables the XCD-aware mapping in the kernel
-        split = (split + 7) & ~7;
-        rows = (int)round_up(cdiv(M, split), BK);
-        if ((long)rows * (split - 1) >= M) { split = cdiv(M, rows); }      // keep every chunk non-empty; falls back to the identity map
-    }
     dim3 grid(jt, it, split);
     if (BIv == 32) hipLaunchKernelGGL((k_conv_wgrad<T, AMODE, 32>), grid, dim3(NT), 0, st, a, rows);
     else if (BIv == 64) hipLaunchKernelGGL((k_conv_wgrad<T, AMODE, 64>), grid, dim3(NT), 0, st, a, rows);
