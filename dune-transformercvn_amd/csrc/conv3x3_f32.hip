@@ -1,0 +1,183 @@
+// fp32 (parity mode) 3x3 convolutions of the DenseNet bottleneck layers on padded LDS tiles: forward, data gradient and weight
+// gradient of conv2 (128 -> growth <= 32 channels; reference: transformercvn/network/layers/dense_net.py:29-40 and its autograd).
+//
+// Same padded index space as the bf16 tile kernels (tile3x3.h): a workgroup stages ONE transformed image of 128 + 2*(W+3)
+// consecutive padded positions in LDS, so BatchNorm + PReLU run once per element instead of once per tap and the nine taps are
+// plain row offsets.  Arithmetic is v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, 64 cycles per instruction): one operand float
+// per lane, so fragments are read from LDS as 4-byte words along the contiguous channel axis -- no transposes, no swizzles:
+//   weight gradient  C[n][c] (per tap) = sum_pos eff[pos][n] * img[pos + shift(tap)][c]:  36 (tap, 32-channel) tiles, nine per wave
+//                    (144 accumulator registers), A = eff^T and B = img both read along their channel axis;
+//   forward          each wave owns a quarter of K (32 input channels x 9 taps, its 144 weight floats register resident) for all
+//                    128 positions, the four partial tiles are summed through LDS in the epilogue;
+//   data gradient    each wave owns 32 of the 128 output channels (144 weight floats register resident) for all 128 positions.
+// All three are bound by the fp32 matrix pipe (576 MFMAs per wave and tile = 15 us) once the image is staged.
+#include "prof.h"
+#include "tcvn_ops.h"
+#include "tile3x3.h"
+
+namespace tcvn {
+
+using namespace t3;
+
+namespace {
+
+constexpr int C128 = 128;
+
+__device__ __forceinline__ int fdiv_(int a, int d, float inv, int& rem) {
+    int q = (int)((float)a * inv);
+    rem = a - q * d;
+    if (rem < 0) { --q; rem += d; }
+    else if (rem >= d) { ++q; rem -= d; }
+    return q;
+}
+__device__ __forceinline__ int pix_of_(const PadGeom& q, int g, float invWp, float invHp) {
+    if (g < 0 || g >= (int)q.gtot) return -1;
+    int wp, hp;
+    const int row = fdiv_(g, q.Wp, invWp, wp);
+    const int img = fdiv_(row, q.Hp, invHp, hp);
+    if (hp < 1 || hp > q.H || wp < 1 || wp > q.W) return -1;
+    return (img * q.H + (hp - 1)) * q.W + (wp - 1);
+}
+
+// image rows [0, nrows): prelu(sc*y + sh, sl) of Y[tbl[row]] (zeros for padding), row stride IS floats
+template <int IS>
+__device__ __forceinline__ void stage_image(float* img, const int* tbl, int nrows, const float* __restrict__ Y, long lda,
+                                            const float* sc, const float* sh, const float* sl) {
+    const int ch = threadIdx.x & 31, r0 = threadIdx.x >> 5;                 // 16-B chunk, row lane
+    const float4 vsc = *reinterpret_cast<const float4*>(sc + ch * 4), vsh = *reinterpret_cast<const float4*>(sh + ch * 4),
+                 vsl = *reinterpret_cast<const float4*>(sl + ch * 4);
+    for (int rr = r0; rr < nrows; rr += 8) {
+        const int m = tbl[rr];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m >= 0) {
+            const float4 y = *reinterpret_cast<const float4*>(Y + (long)m * lda + ch * 4);
+            v.x = prelu(fmaf(y.x, vsc.x, vsh.x), vsl.x); v.y = prelu(fmaf(y.y, vsc.y, vsh.y), vsl.y);
+            v.z = prelu(fmaf(y.z, vsc.z, vsh.z), vsl.z); v.w = prelu(fmaf(y.w, vsc.w, vsh.w), vsl.w);
+        }
+        float* d = img + rr * IS + ch * 4;
+        if (IS % 4 == 0) *reinterpret_cast<float4*>(d) = v;
+        else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+    }
+}
+
+// eff[pos][n] = drop * (G + P*x + Q) of the layer's output slice for the TP positions starting at row `first` of tbl; row stride ES
+template <int ES>
+__device__ __forceinline__ void stage_eff(float* eff, const int* tbl, int first, int nrows, const EffSrc& e, float* bsum) {
+    const float* __restrict__ G = reinterpret_cast<const float*>(e.G);
+    const float* __restrict__ X = reinterpret_cast<const float*>(e.X);
+    const int n = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    const bool nok = n < e.N;
+    const float P = nok ? e.P[n] : 0.f, Q = nok ? e.Q[n] : 0.f;
+    float s = 0.f;
+    for (int rr = r0; rr < nrows; rr += 8) {
+        const int m = tbl[first + rr];
+        float v = 0.f;
+        if (m >= 0 && nok) {
+            v = G[(long)m * e.ldg + e.c_off + n] + P * X[(long)m * e.ldx + e.c_off + n] + Q;
+            if (e.drop_p > 0.f) v *= drop_scale_mn(e.drop_p, e.seed, e.stream_id, m, n, e.N);
+        }
+        eff[rr * ES + n] = v;
+        s += v;
+    }
+    if (bsum) *bsum += s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_f32(const ConvWgradArgs g, int n_img, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const ConvFwdArgs& fa = g.fa;
+    const PadGeom q(n_img, fa.H, fa.W);
+    const int nrows = q.rows();
+    float* img = smf;                                     // [nrows][128]
+    float* eff = img + nrows * C128;                      // [TP][32]
+    int* tbl = reinterpret_cast<int*>(eff + TP * 32);     // [nrows]
+    float* bred = reinterpret_cast<float*>(tbl + ((nrows + 3) & ~3));      // [8][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
+    const float* __restrict__ Y = reinterpret_cast<const float*>(fa.A);
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float bsum = 0.f;
+    // this wave's nine (tap, 32-channel tile) pairs: pair = wave*9 + i -> tap = pair >> 2, ct = pair & 3
+    int boff[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int pair = wave * 9 + i, tap = pair >> 2, ct = pair & 3;
+        boff[i] = (q.halo + (tap / 3 - 1) * q.Wp + (tap % 3 - 1)) * C128 + ct * 32 + l31;
+    }
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();
+        for (int rr = tid; rr < nrows; rr += 256) tbl[rr] = pix_of_(q, t * TP - q.halo + rr, invWp, invHp);
+        __syncthreads();
+        stage_image<C128>(img, tbl, nrows, Y, fa.lda, fa.sc, fa.sh, fa.sl);
+        stage_eff<32>(eff, tbl, q.halo, TP, g.e, &bsum);
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < TP / 2; ++ks) {
+            const int pos = 2 * ks + lh;
+            const float a = eff[pos * 32 + l31];
+            const float* bp = img + pos * C128;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[boff[i]], acc[i], 0, 0, 0);
+        }
+    }
+    // dWk[n][tap*128 + c] += acc ; accumulator row = output channel n, column = input channel within the tile
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int pair = wave * 9 + i, tap = pair >> 2, ct = pair & 3;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (n < g.e.N) atomicAdd(g.dWk + (long)n * fa.Kp + tap * C128 + ct * 32 + l31, acc[i][e]);
+        }
+    }
+    if (g.dbias != nullptr) {
+        __syncthreads();
+        bred[(tid >> 5) * 32 + (tid & 31)] = bsum;
+        __syncthreads();
+        if (tid < 32 && tid < g.e.N) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += bred[r * 32 + tid];
+            atomicAdd(g.dbias + tid, s);
+        }
+    }
+}
+
+size_t wgrad_f32_smem(const PadGeom& q) { return ((size_t)q.rows() * C128 + TP * 32 + ((q.rows() + 3) & ~3) + 8 * 32) * 4; }
+
+int grid_f32(long ntiles) { return (int)(ntiles < 256 ? ntiles : 256); }
+
+}  // namespace
+
+bool conv3x3_wgrad_f32_ok(const ConvWgradArgs& a) {
+    const ConvFwdArgs& f = a.fa;
+    if (a.mode != MODE_F32 || f.amode != A_3X3 || f.C != C128 || f.lda != C128 || a.e.N > 32 || f.Kp != 9 * C128 || a.nfast) return false;
+    if (f.M % (f.H * f.W) != 0 || (reinterpret_cast<uintptr_t>(f.A) & 15)) return false;
+    const PadGeom q(f.M / (f.H * f.W), f.H, f.W);
+    return q.gtot < (1L << 30) && wgrad_f32_smem(q) <= 160 * 1024;
+}
+
+int conv3x3_wgrad_f32(const ConvWgradArgs& a, hipStream_t st) {
+    const ConvFwdArgs& f = a.fa;
+    const int n_img = f.M / (f.H * f.W);
+    const PadGeom q(n_img, f.H, f.W);
+    const int ntiles = (int)q.tiles();
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wgrad_f32), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    ProfScope ps("k_conv3x3_wgrad_f32", 2.0 * f.M * (double)a.e.N * f.K, (double)f.M * 4.0 * (f.C + 2 * a.e.N), st);
+    hipLaunchKernelGGL(k_conv3x3_wgrad_f32, dim3(grid_f32(ntiles)), dim3(256), wgrad_f32_smem(q), st, a, n_img, ntiles);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace tcvn

@@ -138,6 +138,9 @@ struct ConvWgradArgs {
 };
 int conv_wgrad(const ConvWgradArgs& a, hipStream_t st);
 bool conv3x3_wgrad_tile_ok(const ConvWgradArgs& a);
+// fp32 padded-tile 3x3 kernels (conv3x3_f32.hip): parity mode, C = 128 -> N <= 32
+bool conv3x3_wgrad_f32_ok(const ConvWgradArgs& a);
+int conv3x3_wgrad_f32(const ConvWgradArgs& a, hipStream_t st);
 int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st);
 
 // Reduce the backward partials of one BatchNorm, emit parameter gradients and the (P, Q) coefficients of its input.
