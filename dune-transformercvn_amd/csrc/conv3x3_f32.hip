@@ -150,6 +150,180 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_f32(const ConvWgradArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: Out[pos][n_off + n] = drop * (bias[n] + sum_tap sum_c img[pos + shift(tap)][c] * Wk[n][tap*128 + c]), statistics
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int ISF = 129;          // image row stride in floats: A fragments run along positions -> odd stride, conflict free
+
+__global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_f32(const ConvFwdArgs g, int n_img, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const PadGeom q(n_img, g.H, g.W);
+    const int nrows = q.rows();
+    float* img = smf;                                             // [nrows][ISF]; later the 4 partial tiles [4][TP][32]
+    int* tbl = reinterpret_cast<int*>(img + nrows * ISF);         // [nrows]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
+    const float* __restrict__ Y = reinterpret_cast<const float*>(g.A);
+    const float* __restrict__ Wk = reinterpret_cast<const float*>(g.Wk);
+    float* __restrict__ Out = reinterpret_cast<float*>(g.Out);
+    // this wave's quarter of K: input channels [32*wave, +32) of every tap; B[k][j = n]: lane holds Wk[n = l31][tap*128 + 32*wave + 2*kk + lh]
+    float bw[144];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            bw[tap * 16 + kk] = l31 < g.N ? Wk[(long)l31 * g.Kp + tap * C128 + wave * 32 + 2 * kk + lh] : 0.f;
+    // epilogue role: position pos = tid >> 1, channels [16*(tid&1), +16)
+    const int epos = tid >> 1, en0 = (tid & 1) * 16;
+    float ebias[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ebias[j] = en0 + j < g.N ? g.bias[en0 + j] : 0.f;
+    double s1[16], s2[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { s1[j] = 0; s2[j] = 0; }
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();
+        for (int rr = tid; rr < nrows; rr += 256) tbl[rr] = pix_of_(q, t * TP - q.halo + rr, invWp, invHp);
+        __syncthreads();
+        stage_image<ISF>(img, tbl, nrows, Y, g.lda, g.sc, g.sh, g.sl);
+        __syncthreads();
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* ap = img + (q.halo + (tap / 3 - 1) * q.Wp + (tap % 3 - 1) + l31) * ISF + wave * 32 + lh;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[pt * 32 * ISF + 2 * kk], bw[tap * 16 + kk], acc[pt], 0, 0, 0);
+        }
+        __syncthreads();                                          // every wave is done reading the image
+        float* part = img;                                        // [4][TP][32]
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                part[((wave * TP) + pt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + l31] = acc[pt][e];
+        __syncthreads();
+        const int m = tbl[q.halo + epos];
+        if (m >= 0) {
+            float v[16];
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                float4 sum = *reinterpret_cast<const float4*>(part + epos * 32 + en0 + j4 * 4);
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const float4 p = *reinterpret_cast<const float4*>(part + (w * TP + epos) * 32 + en0 + j4 * 4);
+                    sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+                }
+                v[j4 * 4] = sum.x; v[j4 * 4 + 1] = sum.y; v[j4 * 4 + 2] = sum.z; v[j4 * 4 + 3] = sum.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int n = en0 + j;
+                if (n < g.N) {
+                    float o = v[j] + ebias[j];
+                    if (g.drop_p > 0.f) o *= drop_scale_mn(g.drop_p, g.seed, g.stream_id, m, n, g.N);
+                    Out[(long)m * g.ldo + g.n_off + n] = o;
+                    s1[j] += (double)o; s2[j] += (double)o * o;
+                }
+            }
+        }
+    }
+    if (g.part != nullptr) {                                      // per-channel sums of this workgroup: reduce the 128 threads of each channel half
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smf);             // [256][2] per channel slot j, processed 4 channels at a time
+        for (int j0 = 0; j0 < 16; j0 += 1) {
+            red[tid * 2] = s1[j0]; red[tid * 2 + 1] = s2[j0];
+            __syncthreads();
+            if (tid < 2) {                                        // tid = channel half
+                double a = 0, b = 0;
+                for (int r = tid; r < 256; r += 2) { a += red[r * 2]; b += red[r * 2 + 1]; }
+                const int n = tid * 16 + j0;
+                if (n < g.N) { double* p = g.part + ((long)blockIdx.x * g.N + n) * 2; p[0] = a; p[1] = b; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// data gradient (N = 32 output-gradient channels): dA[pos][c] = sum_tap sum_n eff[pos - shift(tap)][n] * Wt[c][tap*32 + n], then the
+// PReLU + BatchNorm backward of norm2 on Y: u = sc*y + sh ; dU = dA * prelu'(u) ; Gout = sc*dU ; sums (dU, dU*y, dA*min(u,0))
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int ESD = 33;
+
+__global__ __launch_bounds__(256, 1) void k_conv3x3_dgrad_f32(const ConvDgradArgs g, int n_img, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const PadGeom q(n_img, g.H, g.W);
+    const int nrows = q.rows();
+    float* eff = smf;                                             // [nrows][ESD]
+    int* tbl = reinterpret_cast<int*>(eff + nrows * ESD);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
+    const float* __restrict__ Wt = reinterpret_cast<const float*>(g.Wt);
+    const float* __restrict__ Yin = reinterpret_cast<const float*>(g.Xin);
+    float* __restrict__ Gout = reinterpret_cast<float*>(g.Gout);
+    const int c = wave * 32 + l31;                                // this lane's output channel
+    float bw[144];                                                // B[k = tap*32 + n][j = c]: Wt[c][2*kk + lh]
+#pragma unroll
+    for (int kk = 0; kk < 144; ++kk) bw[kk] = Wt[(long)c * g.Kp + 2 * kk + lh];
+    const float sc = g.sc[c], sh = g.sh[c], sl = g.sl[c];
+    double s1 = 0, s2 = 0, s3 = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();
+        for (int rr = tid; rr < nrows; rr += 256) tbl[rr] = pix_of_(q, t * TP - q.halo + rr, invWp, invHp);
+        __syncthreads();
+        stage_eff<ESD>(eff, tbl, 0, nrows, g.e, nullptr);
+        __syncthreads();
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* ap = eff + (q.halo - ((tap / 3 - 1) * q.Wp + (tap % 3 - 1)) + l31) * ESD + lh;     // source = pos - shift(tap)
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+                    acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[pt * 32 * ESD + 2 * kk], bw[tap * 16 + kk], acc[pt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = tbl[q.halo + pt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh];
+                if (m >= 0) {
+                    const float y = Yin[(long)m * g.ldxin + c];
+                    const float u = fmaf(y, sc, sh);
+                    const float dA = acc[pt][e];
+                    const float du = u > 0.f ? dA : sl * dA;
+                    s1 += du; s2 += (double)du * y; s3 += u > 0.f ? 0.f : dA * u;
+                    Gout[(long)m * g.ldgo + c] = sc * du;
+                }
+            }
+    }
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
+    if (lh == 0) {
+        double* p = g.part + ((long)blockIdx.x * g.N + c) * 3;
+        p[0] = s1; p[1] = s2; p[2] = s3;
+    }
+}
+
+size_t fwd_f32_smem(const PadGeom& q) {
+    const size_t img = (size_t)q.rows() * ISF, part = 4 * TP * 32;
+    return ((img > part ? img : part) + ((q.rows() + 3) & ~3)) * 4 + 64;
+}
+size_t dgrad_f32_smem(const PadGeom& q) { return ((size_t)q.rows() * ESD + ((q.rows() + 3) & ~3)) * 4 + 64; }
+
 size_t wgrad_f32_smem(const PadGeom& q) { return ((size_t)q.rows() * C128 + TP * 32 + ((q.rows() + 3) & ~3) + 8 * 32) * 4; }
 
 int grid_f32(long ntiles) { return (int)(ntiles < 256 ? ntiles : 256); }
@@ -180,4 +354,50 @@ int conv3x3_wgrad_f32(const ConvWgradArgs& a, hipStream_t st) {
     return 0;
 }
 
+}  // namespace tcvn
+
+namespace tcvn {
+bool conv3x3_fwd_f32_ok(const ConvFwdArgs& a) {
+    if (a.mode != MODE_F32 || a.amode != A_3X3 || a.C != C128 || a.lda != C128 || a.N > 32 || a.Kp != 9 * C128) return false;
+    if (a.M % (a.H * a.W) != 0 || (reinterpret_cast<uintptr_t>(a.A) & 15) || (a.ldo & 3) || (a.n_off & 3) ||
+        (reinterpret_cast<uintptr_t>(a.Out) & 15)) return false;
+    const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
+    return q.gtot < (1L << 30) && fwd_f32_smem(q) <= 160 * 1024 && 256 * 2 * 8 <= (long)fwd_f32_smem(q);
+}
+int conv3x3_fwd_f32_nblk(const ConvFwdArgs& a) { return grid_f32(PadGeom(a.M / (a.H * a.W), a.H, a.W).tiles()); }
+int conv3x3_fwd_f32(const ConvFwdArgs& a, hipStream_t st) {
+    const int n_img = a.M / (a.H * a.W);
+    const PadGeom q(n_img, a.H, a.W);
+    const int ntiles = (int)q.tiles();
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_fwd_f32), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    ProfScope ps("k_conv3x3_fwd_f32", 2.0 * a.M * (double)a.N * a.K, (double)a.M * 4.0 * (a.C + a.N), st);
+    hipLaunchKernelGGL(k_conv3x3_fwd_f32, dim3(grid_f32(ntiles)), dim3(256), fwd_f32_smem(q), st, a, n_img, ntiles);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+bool conv3x3_dgrad_f32_ok(const ConvDgradArgs& a) {
+    if (a.mode != MODE_F32 || a.dmode != DG_3X3 || a.N != C128 || a.e.N != 32 || a.Kp != 288 || a.accumulate || a.ldxin != C128) return false;
+    if (a.M % (a.H * a.W) != 0) return false;
+    const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
+    return q.gtot < (1L << 30) && dgrad_f32_smem(q) <= 160 * 1024;
+}
+int conv3x3_dgrad_f32_nblk(const ConvDgradArgs& a) { return grid_f32(PadGeom(a.M / (a.H * a.W), a.H, a.W).tiles()); }
+int conv3x3_dgrad_f32(const ConvDgradArgs& a, hipStream_t st) {
+    const int n_img = a.M / (a.H * a.W);
+    const PadGeom q(n_img, a.H, a.W);
+    const int ntiles = (int)q.tiles();
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_dgrad_f32), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    ProfScope ps("k_conv3x3_dgrad_f32", 2.0 * a.M * (double)a.N * 9 * a.e.N, (double)a.M * 4.0 * (2 * a.e.N + 2 * a.N), st);
+    hipLaunchKernelGGL(k_conv3x3_dgrad_f32, dim3(grid_f32(ntiles)), dim3(256), dgrad_f32_smem(q), st, a, n_img, ntiles);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
 }  // namespace tcvn

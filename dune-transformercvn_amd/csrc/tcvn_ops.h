@@ -139,6 +139,12 @@ struct ConvWgradArgs {
 int conv_wgrad(const ConvWgradArgs& a, hipStream_t st);
 bool conv3x3_wgrad_tile_ok(const ConvWgradArgs& a);
 // fp32 padded-tile 3x3 kernels (conv3x3_f32.hip): parity mode, C = 128 -> N <= 32
+bool conv3x3_fwd_f32_ok(const ConvFwdArgs& a);
+int conv3x3_fwd_f32_nblk(const ConvFwdArgs& a);
+int conv3x3_fwd_f32(const ConvFwdArgs& a, hipStream_t st);
+bool conv3x3_dgrad_f32_ok(const ConvDgradArgs& a);
+int conv3x3_dgrad_f32_nblk(const ConvDgradArgs& a);
+int conv3x3_dgrad_f32(const ConvDgradArgs& a, hipStream_t st);
 bool conv3x3_wgrad_f32_ok(const ConvWgradArgs& a);
 int conv3x3_wgrad_f32(const ConvWgradArgs& a, hipStream_t st);
 int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st);
