@@ -23,6 +23,15 @@ namespace {
 
 constexpr int C128 = 128;
 
+#ifdef TCVN_PHASE_PROF
+__device__ unsigned long long g_ph[32];
+#define PH_INIT long long ph_last = clock64();
+#define PH(i) if (threadIdx.x == 0) { const long long ph_now = clock64(); atomicAdd(&g_ph[i], (unsigned long long)(ph_now - ph_last)); ph_last = ph_now; }
+#else
+#define PH_INIT
+#define PH(i)
+#endif
+
 __device__ __forceinline__ int fdiv_(int a, int d, float inv, int& rem) {
     int q = (int)((float)a * inv);
     rem = a - q * d;
@@ -39,29 +48,43 @@ __device__ __forceinline__ int pix_of_(const PadGeom& q, int g, float invWp, flo
     return (img * q.H + (hp - 1)) * q.W + (wp - 1);
 }
 
-// image rows [0, nrows): prelu(sc*y + sh, sl) of Y[tbl[row]] (zeros for padding), row stride IS floats
-template <int IS>
+// image rows [0, nrows): prelu(sc*y + sh, sl) of Y[tbl[row]] (zeros for padding), row stride IS floats.  Loads are issued in
+// batches of SB rows per thread before any of them is consumed: one workgroup per CU cannot hide a dependent load per row.
+template <int IS, int SB>
 __device__ __forceinline__ void stage_image(float* img, const int* tbl, int nrows, const float* __restrict__ Y, long lda,
                                             const float* sc, const float* sh, const float* sl) {
     const int ch = threadIdx.x & 31, r0 = threadIdx.x >> 5;                 // 16-B chunk, row lane
-    const float4 vsc = *reinterpret_cast<const float4*>(sc + ch * 4), vsh = *reinterpret_cast<const float4*>(sh + ch * 4),
-                 vsl = *reinterpret_cast<const float4*>(sl + ch * 4);
-    for (int rr = r0; rr < nrows; rr += 8) {
-        const int m = tbl[rr];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m >= 0) {
-            const float4 y = *reinterpret_cast<const float4*>(Y + (long)m * lda + ch * 4);
-            v.x = prelu(fmaf(y.x, vsc.x, vsh.x), vsl.x); v.y = prelu(fmaf(y.y, vsc.y, vsh.y), vsl.y);
-            v.z = prelu(fmaf(y.z, vsc.z, vsh.z), vsl.z); v.w = prelu(fmaf(y.w, vsc.w, vsh.w), vsl.w);
+    const f32x4 vsc = *reinterpret_cast<const f32x4*>(sc + ch * 4), vsh = *reinterpret_cast<const f32x4*>(sh + ch * 4),
+                vsl = *reinterpret_cast<const f32x4*>(sl + ch * 4);
+    for (int rb = r0; rb < nrows; rb += 8 * SB) {
+        f32x4 y[SB];
+        int mm[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) mm[u] = rb + 8 * u < nrows ? tbl[rb + 8 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            y[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (mm[u] >= 0) y[u] = *reinterpret_cast<const f32x4*>(Y + (long)mm[u] * lda + ch * 4);
         }
-        float* d = img + rr * IS + ch * 4;
-        if (IS % 4 == 0) *reinterpret_cast<float4*>(d) = v;
-        else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int rr = rb + 8 * u;
+            if (rr < nrows) {
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (mm[u] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = prelu(fmaf(y[u][j], vsc[j], vsh[j]), vsl[j]);
+                }
+                float* d = img + rr * IS + ch * 4;
+                if (IS % 4 == 0) *reinterpret_cast<f32x4*>(d) = v;
+                else { d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+            }
+        }
     }
 }
 
-// eff[pos][n] = drop * (G + P*x + Q) of the layer's output slice for the TP positions starting at row `first` of tbl; row stride ES
-template <int ES>
+// eff[pos][n] = drop * (G + P*x + Q) of the layer's output slice for nrows rows starting at row `first` of tbl; row stride ES
+template <int ES, int SB>
 __device__ __forceinline__ void stage_eff(float* eff, const int* tbl, int first, int nrows, const EffSrc& e, float* bsum) {
     const float* __restrict__ G = reinterpret_cast<const float*>(e.G);
     const float* __restrict__ X = reinterpret_cast<const float*>(e.X);
@@ -69,15 +92,29 @@ __device__ __forceinline__ void stage_eff(float* eff, const int* tbl, int first,
     const bool nok = n < e.N;
     const float P = nok ? e.P[n] : 0.f, Q = nok ? e.Q[n] : 0.f;
     float s = 0.f;
-    for (int rr = r0; rr < nrows; rr += 8) {
-        const int m = tbl[first + rr];
-        float v = 0.f;
-        if (m >= 0 && nok) {
-            v = G[(long)m * e.ldg + e.c_off + n] + P * X[(long)m * e.ldx + e.c_off + n] + Q;
-            if (e.drop_p > 0.f) v *= drop_scale_mn(e.drop_p, e.seed, e.stream_id, m, n, e.N);
+    for (int rb = r0; rb < nrows; rb += 8 * SB) {
+        float gv[SB], xv[SB];
+        int mm[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) mm[u] = (rb + 8 * u < nrows && nok) ? tbl[first + rb + 8 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            gv[u] = 0.f; xv[u] = 0.f;
+            if (mm[u] >= 0) { gv[u] = G[(long)mm[u] * e.ldg + e.c_off + n]; xv[u] = X[(long)mm[u] * e.ldx + e.c_off + n]; }
         }
-        eff[rr * ES + n] = v;
-        s += v;
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int rr = rb + 8 * u;
+            if (rr < nrows) {
+                float v = 0.f;
+                if (mm[u] >= 0) {
+                    v = gv[u] + P * xv[u] + Q;
+                    if (e.drop_p > 0.f) v *= drop_scale_mn(e.drop_p, e.seed, e.stream_id, mm[u], n, e.N);
+                }
+                eff[rr * ES + n] = v;
+                s += v;
+            }
+        }
     }
     if (bsum) *bsum += s;
 }
@@ -111,13 +148,17 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_f32(const ConvWgradArg
         const int pair = wave * 9 + i, tap = pair >> 2, ct = pair & 3;
         boff[i] = (q.halo + (tap / 3 - 1) * q.Wp + (tap % 3 - 1)) * C128 + ct * 32 + l31;
     }
+    PH_INIT
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         __syncthreads();
+        PH(0)
         for (int rr = tid; rr < nrows; rr += 256) tbl[rr] = pix_of_(q, t * TP - q.halo + rr, invWp, invHp);
         __syncthreads();
-        stage_image<C128>(img, tbl, nrows, Y, fa.lda, fa.sc, fa.sh, fa.sl);
-        stage_eff<32>(eff, tbl, q.halo, TP, g.e, &bsum);
+        PH(1)
+        stage_image<C128, 17>(img, tbl, nrows, Y, fa.lda, fa.sc, fa.sh, fa.sl);
+        stage_eff<32, 16>(eff, tbl, q.halo, TP, g.e, &bsum);
         __syncthreads();
+        PH(2)
 #pragma unroll 2
         for (int ks = 0; ks < TP / 2; ++ks) {
             const int pos = 2 * ks + lh;
@@ -182,12 +223,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_f32(const ConvFwdArgs g,
     double s1[16], s2[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) { s1[j] = 0; s2[j] = 0; }
+    PH_INIT
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         __syncthreads();
+        PH(8)
         for (int rr = tid; rr < nrows; rr += 256) tbl[rr] = pix_of_(q, t * TP - q.halo + rr, invWp, invHp);
         __syncthreads();
-        stage_image<ISF>(img, tbl, nrows, Y, g.lda, g.sc, g.sh, g.sl);
+        PH(9)
+        stage_image<ISF, 17>(img, tbl, nrows, Y, g.lda, g.sc, g.sh, g.sl);
         __syncthreads();
+        PH(10)
         f32x16 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -203,6 +248,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_f32(const ConvFwdArgs g,
                     acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[pt * 32 * ISF + 2 * kk], bw[tap * 16 + kk], acc[pt], 0, 0, 0);
         }
         __syncthreads();                                          // every wave is done reading the image
+        PH(11)
         float* part = img;                                        // [4][TP][32]
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt)
@@ -226,12 +272,19 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_f32(const ConvFwdArgs g,
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int n = en0 + j;
-                if (n < g.N) {
-                    float o = v[j] + ebias[j];
-                    if (g.drop_p > 0.f) o *= drop_scale_mn(g.drop_p, g.seed, g.stream_id, m, n, g.N);
-                    Out[(long)m * g.ldo + g.n_off + n] = o;
-                    s1[j] += (double)o; s2[j] += (double)o * o;
-                }
+                float o = v[j] + ebias[j];
+                if (g.drop_p > 0.f && n < g.N) o *= drop_scale_mn(g.drop_p, g.seed, g.stream_id, m, n, g.N);
+                v[j] = o;
+                if (n < g.N) { s1[j] += (double)o; s2[j] += (double)o * o; }
+            }
+            float* op = Out + (long)m * g.ldo + g.n_off + en0;
+            if (g.N == 32) {
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) *reinterpret_cast<f32x4*>(op + j4 * 4) = f32x4{v[j4 * 4], v[j4 * 4 + 1], v[j4 * 4 + 2], v[j4 * 4 + 3]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (en0 + j < g.N) op[j] = v[j];
             }
         }
     }
@@ -276,12 +329,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_dgrad_f32(const ConvDgradArg
     for (int kk = 0; kk < 144; ++kk) bw[kk] = Wt[(long)c * g.Kp + 2 * kk + lh];
     const float sc = g.sc[c], sh = g.sh[c], sl = g.sl[c];
     double s1 = 0, s2 = 0, s3 = 0;
+    PH_INIT
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         __syncthreads();
+        PH(16)
         for (int rr = tid; rr < nrows; rr += 256) tbl[rr] = pix_of_(q, t * TP - q.halo + rr, invWp, invHp);
         __syncthreads();
-        stage_eff<ESD>(eff, tbl, 0, nrows, g.e, nullptr);
+        PH(17)
+        stage_eff<ESD, 17>(eff, tbl, 0, nrows, g.e, nullptr);
         __syncthreads();
+        PH(18)
         f32x16 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -296,20 +353,29 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_dgrad_f32(const ConvDgradArg
                 for (int pt = 0; pt < 4; ++pt)
                     acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[pt * 32 * ESD + 2 * kk], bw[tap * 16 + kk], acc[pt], 0, 0, 0);
         }
+        PH(19)
+        // epilogue in batches of 16 rows: all loads of a batch are in flight before the first is used
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
+        for (int pt = 0; pt < 4; ++pt) {
+            int mm[16];
+            float yv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mm[e] = tbl[q.halo + pt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yv[e] = Yin[(long)(mm[e] < 0 ? 0 : mm[e]) * g.ldxin + c];
+            float f1 = 0.f, f3 = 0.f;
+            double d2 = 0;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = tbl[q.halo + pt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh];
-                if (m >= 0) {
-                    const float y = Yin[(long)m * g.ldxin + c];
-                    const float u = fmaf(y, sc, sh);
-                    const float dA = acc[pt][e];
-                    const float du = u > 0.f ? dA : sl * dA;
-                    s1 += du; s2 += (double)du * y; s3 += u > 0.f ? 0.f : dA * u;
-                    Gout[(long)m * g.ldgo + c] = sc * du;
-                }
+                const bool ok = mm[e] >= 0;
+                const float y = yv[e], u = fmaf(y, sc, sh);
+                const float dA = ok ? acc[pt][e] : 0.f;
+                const float du = u > 0.f ? dA : sl * dA;
+                f1 += du; d2 += (double)du * y; f3 += u > 0.f ? 0.f : dA * u;
+                if (ok) Gout[(long)mm[e] * g.ldgo + c] = sc * du;
             }
+            s1 += f1; s2 += d2; s3 += f3;
+        }
     }
     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
     if (lh == 0) {
@@ -401,3 +467,11 @@ int conv3x3_dgrad_f32(const ConvDgradArgs& a, hipStream_t st) {
     return 0;
 }
 }  // namespace tcvn
+
+#ifdef TCVN_PHASE_PROF
+extern "C" int tcvn_debug_phases(unsigned long long* out32, int reset) {
+    hipMemcpyFromSymbol(out32, HIP_SYMBOL(tcvn::g_ph), 32 * 8);
+    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(tcvn::g_ph), z, 32 * 8); }
+    return 0;
+}
+#endif

@@ -379,6 +379,7 @@ int wgrad_mode(const ConvWgradArgs& a, hipStream_t st) {
 int conv_dgrad_nblk(const ConvDgradArgs& a) {
     if (conv3x3_dgrad_tile_ok(a)) return conv3x3_dgrad_tile_nblk(a);
     if (conv3x3_dgrad_f32_ok(a)) return conv3x3_dgrad_f32_nblk(a);
+    if (conv1x1_dgrad_f32_ok(a)) return conv1x1_dgrad_f32_nblk(a);
     return conv_fwd_grid(a.M);
 }
 
@@ -388,6 +389,7 @@ int conv_dgrad(const ConvDgradArgs& a, hipStream_t st) {
     if (a.nblk != conv_dgrad_nblk(a)) { fprintf(stderr, "tcvn: conv_dgrad nblk mismatch\n"); return -3; }
     if (conv3x3_dgrad_tile_ok(a)) return conv3x3_dgrad_tile(a, st);
     if (conv3x3_dgrad_f32_ok(a)) return conv3x3_dgrad_f32(a, st);
+    if (conv1x1_dgrad_f32_ok(a)) return conv1x1_dgrad_f32(a, st);
     char nm[96];
     snprintf(nm, sizeof(nm), "k_conv_dgrad<%s,%d,%d>", a.mode == MODE_F32 ? "float" : "bf16", a.dmode, a.N <= 32 ? 32 : a.N <= 64 ? 64 : 128);
     ProfScope ps(nm, 2.0 * a.M * (double)a.N * ((a.dmode == DG_3X3 ? 9 : 1) * a.e.N), 0.0, st);
@@ -401,6 +403,7 @@ int conv_wgrad(const ConvWgradArgs& a, hipStream_t st) {
         return conv3x3_wgrad_tile(a, st);
     }
     if (conv3x3_wgrad_f32_ok(a)) return conv3x3_wgrad_f32(a, st);
+    if (conv1x1_wgrad_f32_ok(a)) return conv1x1_wgrad_f32(a, st);
     char nm[96];
     snprintf(nm, sizeof(nm), "k_conv_wgrad<%s,%d,%d>", a.mode == MODE_F32 ? "float" : "bf16", a.fa.amode, a.e.N <= 32 ? 32 : a.e.N <= 64 ? 64 : 128);
     ProfScope ps(nm, 2.0 * a.fa.M * (double)a.e.N * a.fa.K, 0.0, st);

@@ -348,10 +348,10 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
         w.mode = mode; w.e = e0; w.dWk = gw_of(s_w0); w.dbias = grad[s_b0];
         w.fa.mode = mode; w.fa.amode = A_STEM; w.fa.A = ws + L.img; w.fa.lda = cfg.in_ch; w.fa.M = (int)M0; w.fa.N = cfg.init_ch;
         w.fa.K = 49 * cfg.in_ch; w.fa.Kp = ef.Kp; w.fa.C = cfg.in_ch; w.fa.H = Hc; w.fa.W = Wc; w.fa.Hin = cfg.H; w.fa.Win = cfg.W;
-        if (mode == MODE_BF16 && conv3x3_tile_enabled() && cfg.in_ch <= 3 && cfg.init_ch <= 64 && last_coords != nullptr) {
+        if (conv3x3_tile_enabled() && cfg.in_ch <= 3 && cfg.init_ch <= 64 && last_coords != nullptr) {
             // conv0 weight gradient from the hit list (bias gradient is exactly zero in exact arithmetic: BN0 follows)
             StemWgradArgs sa{last_coords, last_nnz, ws + L.img, n, cfg.H, cfg.W, cfg.in_ch, e0, Hc, Wc, ef.Kp,
-                             reinterpret_cast<float*>(ws + L.slab), kSlabBytes};
+                             reinterpret_cast<float*>(ws + L.slab), kSlabBytes, mode};
             if ((rc = stem_wgrad_sparse(sa, gw_of(s_w0), st))) return rc;
         } else if ((rc = conv_wgrad(w, st))) return rc;
     }

@@ -87,14 +87,15 @@ __global__ __launch_bounds__(256) void k_pool0_bwd_vec(const Pool0BwdArgs a) {
 }
 
 constexpr int SW_MAXC = 4;
+template <typename T>
 __global__ __launch_bounds__(256, 2) void k_stem_wgrad_sparse(const StemWgradArgs a) {
     __shared__ float wacc[49 * SW_MAXC][64];
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 49 * SW_MAXC * 64; i += 256) (&wacc[0][0])[i] = 0.f;
     __syncthreads();
-    const bf16* img = reinterpret_cast<const bf16*>(a.img);
-    const bf16* G = reinterpret_cast<const bf16*>(a.e.G);
-    const bf16* X = reinterpret_cast<const bf16*>(a.e.X);
+    const T* img = reinterpret_cast<const T*>(a.img);
+    const T* G = reinterpret_cast<const T*>(a.e.G);
+    const T* X = reinterpret_cast<const T*>(a.e.X);
     const int n = lane;
     const bool nok = n < a.e.N;
     const float pn = nok ? a.e.P[n] : 0.f, qn = nok ? a.e.Q[n] : 0.f;
@@ -107,10 +108,10 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad_sparse(const StemWgradArg
         const int y = __builtin_amdgcn_readfirstlane(a.coords[hit * 3 + 1]);
         const int x = __builtin_amdgcn_readfirstlane(a.coords[hit * 3 + 2]);
         if (im < 0 || im >= a.n_img || y < 0 || y >= a.H || x < 0 || x >= a.W) continue;
-        const bf16* px = img + (((long)im * a.H + y) * a.W + x) * a.Cpix;
+        const T* px = img + (((long)im * a.H + y) * a.W + x) * a.Cpix;
         float v[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = c < a.Cpix ? bf2f(px[c]) : 0.f;
+        for (int c = 0; c < 3; ++c) v[c] = c < a.Cpix ? to_f<T>(px[c]) : 0.f;
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky) {
             const int ty = y + 3 - ky;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad_sparse(const StemWgradArg
                 const int tx = x + 3 - kx;
                 if ((tx & 1) || tx < 0 || (tx >> 1) >= a.Wc) continue;
                 const long p = ((long)im * a.Hc + (ty >> 1)) * a.Wc + (tx >> 1);
-                const float eff = nok ? bf2f(G[p * a.e.ldg + n]) + pn * bf2f(X[p * a.e.ldx + n]) + qn : 0.f;
+                const float eff = nok ? to_f<T>(G[p * a.e.ldg + n]) + pn * to_f<T>(X[p * a.e.ldx + n]) + qn : 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) acc[ky * 7 + kx][c] = fmaf(v[c], eff, acc[ky * 7 + kx][c]);
             }
@@ -146,13 +147,25 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad_sparse(const StemWgradArg
 // pooled pixels whose 3x3/2 windows touch the tile is computed ONCE into LDS (fp32); the per-pixel pass then sums its <= 4 windows
 // from LDS instead of re-reading (G, x) of every window from L2 (4 x 256 B per pixel and chunk in k_pool0_bwd_vec).
 constexpr int PB_TH = 8, PB_TW = 32, PB_PH = PB_TH / 2 + 1, PB_PW = PB_TW / 2 + 1;
+template <typename T> __device__ __forceinline__ void store8_g(T* p, const float v[8]);
+template <> __device__ __forceinline__ void store8_g<float>(float* p, const float v[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void store8_g<bf16>(bf16* p, const float v[8]) {
+    u16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(v[j]);
+    *reinterpret_cast<u16x8*>(p) = o;
+}
+template <typename T>
 __global__ __launch_bounds__(256) void k_pool0_bwd_tile(const Pool0BwdArgs a, int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) float effs[PB_PH * PB_PW * 64];
     __shared__ double red[4][8][8][3];
-    const bf16* X = reinterpret_cast<const bf16*>(a.X);
-    const bf16* G = reinterpret_cast<const bf16*>(a.e.G);
-    const bf16* D = reinterpret_cast<const bf16*>(a.e.X);
-    bf16* DU = reinterpret_cast<bf16*>(a.DU);
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* G = reinterpret_cast<const T*>(a.e.G);
+    const T* D = reinterpret_cast<const T*>(a.e.X);
+    T* DU = reinterpret_cast<T*>(a.DU);
     const int tid = threadIdx.x, c8 = tid & 7;
     float sc[8], sh[8], sl[8], cP[8], cQ[8];
 #pragma unroll
@@ -174,10 +187,11 @@ __global__ __launch_bounds__(256) void k_pool0_bwd_tile(const Pool0BwdArgs a, in
             float e8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (ho >= 0 && ho < a.Ho && wo >= 0 && wo < a.Wo) {
                 const long mo = (img * a.Ho + ho) * a.Wo + wo;
-                const u16x8 gv = *reinterpret_cast<const u16x8*>(G + mo * a.e.ldg + c8 * 8);
-                const u16x8 dv = *reinterpret_cast<const u16x8*>(D + mo * a.e.ldx + c8 * 8);
+                float gv[8], dv[8];
+                load8<T>(G + mo * a.e.ldg + c8 * 8, gv);
+                load8<T>(D + mo * a.e.ldx + c8 * 8, dv);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) e8[j] = bf2f(gv[j]) + cP[j] * bf2f(dv[j]) + cQ[j];
+                for (int j = 0; j < 8; ++j) e8[j] = gv[j] + cP[j] * dv[j] + cQ[j];
             }
             float4* o = reinterpret_cast<float4*>(effs + pp * 64 + c8 * 8);
             o[0] = make_float4(e8[0], e8[1], e8[2], e8[3]); o[1] = make_float4(e8[4], e8[5], e8[6], e8[7]);
@@ -205,18 +219,18 @@ __global__ __launch_bounds__(256) void k_pool0_bwd_tile(const Pool0BwdArgs a, in
                 }
             }
             const long p = (img * a.Hin + h) * a.Win + w;
-            const u16x8 xv = *reinterpret_cast<const u16x8*>(X + p * a.C + c8 * 8);
-            u16x8 o;
+            float xv[8], o[8];
+            load8<T>(X + p * a.C + c8 * 8, xv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float z = dz[j] * (1.0f / 9.0f);
-                const float x = bf2f(xv[j]);
+                const float x = xv[j];
                 const float u = fmaf(x, sc[j], sh[j]);
                 const float du = u > 0.f ? z : sl[j] * z;
                 s1[j] += du; s2[j] += (double)du * x; s3[j] += u > 0.f ? 0.f : z * u;
-                o[j] = f2bf(sc[j] * du);
+                o[j] = sc[j] * du;
             }
-            *reinterpret_cast<u16x8*>(DU + p * a.C + c8 * 8) = o;
+            store8_g<T>(DU + p * a.C + c8 * 8, o);
         }
     }
     // threads with equal (tid & 7) hold the same channels: fold lanes 8, 16, 32 apart, then the four waves
@@ -387,14 +401,20 @@ int pool0_bwd_vec_grid(int n_img, int Hin, int Win) {
     return (int)(g < 2048 ? g : 2048);
 }
 bool pool0_bwd_vec_ok(const Pool0BwdArgs& a) {
+    if (a.mode == MODE_F32) return a.C == 64 && (a.e.ldg & 7) == 0 && (a.e.ldx & 7) == 0;      // tile kernel only
     return a.mode == MODE_BF16 && (a.C == 8 || a.C == 16 || a.C == 32 || a.C == 64) && (a.e.ldg & 7) == 0 && (a.e.ldx & 7) == 0;
 }
 int pool0_bwd_vec(const Pool0BwdArgs& a, hipStream_t st) {
     if (!pool0_bwd_vec_ok(a)) return -2;
     if (a.nblk != pool0_bwd_vec_grid(a.n_img, a.Hin, a.Win)) return -3;
     static const bool old = TCVN_KNOB_SET("TCVN_POOL0_BWD_FLAT");        // A/B switch
+    if (a.mode == MODE_F32) {
+        hipLaunchKernelGGL(k_pool0_bwd_tile<float>, dim3(a.nblk), dim3(256), 0, st, a, cdiv(a.Win, PB_TW), cdiv(a.Hin, PB_TH));
+        TCVN_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.C == 64 && !old) {
-        hipLaunchKernelGGL(k_pool0_bwd_tile, dim3(a.nblk), dim3(256), 0, st, a, cdiv(a.Win, PB_TW), cdiv(a.Hin, PB_TH));
+        hipLaunchKernelGGL(k_pool0_bwd_tile<bf16>, dim3(a.nblk), dim3(256), 0, st, a, cdiv(a.Win, PB_TW), cdiv(a.Hin, PB_TH));
         TCVN_LAUNCH_CHECK();
         return 0;
     }
@@ -409,7 +429,8 @@ int stem_wgrad_sparse(const StemWgradArgs& a, float* dWk, hipStream_t st) {
     if ((long)nb * a.e.N * a.Kp * 4 > a.slab_bytes) return -3;
     {
         ProfScope ps("k_stem_wgrad_sparse", 2.0 * a.nnz * 12.25 * a.Cpix * a.e.N, 0.0, st);
-        hipLaunchKernelGGL(k_stem_wgrad_sparse, dim3(nb), dim3(256), 0, st, a);
+        if (a.mode == MODE_F32) hipLaunchKernelGGL(k_stem_wgrad_sparse<float>, dim3(nb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_stem_wgrad_sparse<bf16>, dim3(nb), dim3(256), 0, st, a);
         TCVN_LAUNCH_CHECK();
     }
     return slab_reduce(a.slab, nb, (long)a.e.N * a.Kp, dWk, st);

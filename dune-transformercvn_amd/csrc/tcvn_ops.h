@@ -145,6 +145,12 @@ int conv3x3_fwd_f32(const ConvFwdArgs& a, hipStream_t st);
 bool conv3x3_dgrad_f32_ok(const ConvDgradArgs& a);
 int conv3x3_dgrad_f32_nblk(const ConvDgradArgs& a);
 int conv3x3_dgrad_f32(const ConvDgradArgs& a, hipStream_t st);
+// fp32 1x1 backward kernels (conv1x1_f32.hip): parity mode, Cin <= 512 -> 128 channels
+bool conv1x1_dgrad_f32_ok(const ConvDgradArgs& a);
+int conv1x1_dgrad_f32_nblk(const ConvDgradArgs& a);
+int conv1x1_dgrad_f32(const ConvDgradArgs& a, hipStream_t st);
+bool conv1x1_wgrad_f32_ok(const ConvWgradArgs& a);
+int conv1x1_wgrad_f32(const ConvWgradArgs& a, hipStream_t st);
 bool conv3x3_wgrad_f32_ok(const ConvWgradArgs& a);
 int conv3x3_wgrad_f32(const ConvWgradArgs& a, hipStream_t st);
 int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st);
@@ -229,9 +235,10 @@ int pool0_bwd_vec_grid(int n_img, int Hin, int Win);
 bool pool0_bwd_vec_ok(const Pool0BwdArgs& a);
 int pool0_bwd_vec(const Pool0BwdArgs& a, hipStream_t st);
 struct StemWgradArgs {
-    const int* coords; long nnz; const void* img; int n_img, H, W, Cpix;   // COO hit list + the dense bf16 map [n,H,W,Cpix]
+    const int* coords; long nnz; const void* img; int n_img, H, W, Cpix;   // COO hit list + the dense map [n,H,W,Cpix]
     EffSrc e;                                                                // gradient of the conv0 output [n,Hc,Wc,N]
     int Hc, Wc, Kp; float* slab; long slab_bytes;
+    int mode;                                                                // element type of img / G / X (MODE_F32 or MODE_BF16)
 };
 int stem_wgrad_sparse(const StemWgradArgs& a, float* dWk, hipStream_t st);
 // conv0 forward on an NHWC4 LDS patch (bf16, 3 -> 64 channels, 7x7 / 2)
