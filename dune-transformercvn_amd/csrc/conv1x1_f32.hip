@@ -300,7 +300,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 bool conv1x1_dgrad_f32_ok(const ConvDgradArgs& a) {
     const EffSrc& e = a.e;
-    if (a.mode != MODE_F32 || a.dmode != DG_1X1 || e.N != 128 || a.Kp != 128 || a.N > MAXC || a.N < 1) return false;
+    if (!conv3x3_tile_enabled() || a.mode != MODE_F32 || a.dmode != DG_1X1 || e.N != 128 || a.Kp != 128 || a.N > MAXC || a.N < 1) return false;
     return aligned16(e.G) && aligned16(e.X) && aligned16(a.Wt) && (e.ldg & 3) == 0 && (e.ldx & 3) == 0 && (e.c_off & 3) == 0;
 }
 int conv1x1_dgrad_f32_nblk(const ConvDgradArgs& a) {
@@ -317,7 +317,7 @@ int conv1x1_dgrad_f32(const ConvDgradArgs& a, hipStream_t st) {
 
 bool conv1x1_wgrad_f32_ok(const ConvWgradArgs& a) {
     const ConvFwdArgs& f = a.fa;
-    if (a.mode != MODE_F32 || f.amode != A_1X1 || a.e.N != 128 || a.nfast || f.K > MAXC || f.K < 1 || (f.K & 3)) return false;
+    if (!conv3x3_tile_enabled() || a.mode != MODE_F32 || f.amode != A_1X1 || a.e.N != 128 || a.nfast || f.K > MAXC || f.K < 1 || (f.K & 3)) return false;
     return aligned16(f.A) && (f.lda & 3) == 0;
 }
 int conv1x1_wgrad_f32(const ConvWgradArgs& a, hipStream_t st) {

@@ -398,7 +398,7 @@ int grid_f32(long ntiles) { return (int)(ntiles < 256 ? ntiles : 256); }
 
 bool conv3x3_wgrad_f32_ok(const ConvWgradArgs& a) {
     const ConvFwdArgs& f = a.fa;
-    if (a.mode != MODE_F32 || f.amode != A_3X3 || f.C != C128 || f.lda != C128 || a.e.N > 32 || f.Kp != 9 * C128 || a.nfast) return false;
+    if (!conv3x3_tile_enabled() || a.mode != MODE_F32 || f.amode != A_3X3 || f.C != C128 || f.lda != C128 || a.e.N > 32 || f.Kp != 9 * C128 || a.nfast) return false;
     if (f.M % (f.H * f.W) != 0 || (reinterpret_cast<uintptr_t>(f.A) & 15)) return false;
     const PadGeom q(f.M / (f.H * f.W), f.H, f.W);
     return q.gtot < (1L << 30) && wgrad_f32_smem(q) <= 160 * 1024;
@@ -424,7 +424,7 @@ int conv3x3_wgrad_f32(const ConvWgradArgs& a, hipStream_t st) {
 
 namespace tcvn {
 bool conv3x3_fwd_f32_ok(const ConvFwdArgs& a) {
-    if (a.mode != MODE_F32 || a.amode != A_3X3 || a.C != C128 || a.lda != C128 || a.N > 32 || a.Kp != 9 * C128) return false;
+    if (!conv3x3_tile_enabled() || a.mode != MODE_F32 || a.amode != A_3X3 || a.C != C128 || a.lda != C128 || a.N > 32 || a.Kp != 9 * C128) return false;
     if (a.M % (a.H * a.W) != 0 || (reinterpret_cast<uintptr_t>(a.A) & 15) || (a.ldo & 3) || (a.n_off & 3) ||
         (reinterpret_cast<uintptr_t>(a.Out) & 15)) return false;
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
@@ -446,7 +446,7 @@ int conv3x3_fwd_f32(const ConvFwdArgs& a, hipStream_t st) {
     return 0;
 }
 bool conv3x3_dgrad_f32_ok(const ConvDgradArgs& a) {
-    if (a.mode != MODE_F32 || a.dmode != DG_3X3 || a.N != C128 || a.e.N != 32 || a.Kp != 288 || a.accumulate || a.ldxin != C128) return false;
+    if (!conv3x3_tile_enabled() || a.mode != MODE_F32 || a.dmode != DG_3X3 || a.N != C128 || a.e.N != 32 || a.Kp != 288 || a.accumulate || a.ldxin != C128) return false;
     if (a.M % (a.H * a.W) != 0) return false;
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
     return q.gtot < (1L << 30) && dgrad_f32_smem(q) <= 160 * 1024;

@@ -1,0 +1,188 @@
+// bf16 3x3 / stride 1 / pad 1 convolutions with 64 input and 64 output channels on full-resolution NHWC maps: the layers of the
+// first two stages of the SDXL-style embedder (diffusers ResnetBlock2D conv1 / conv2 at 400x280 and 200x140; reference call
+// site transformercvn/network/layers/sdxl_net.py:27-34, block definitions restated in oracle/sdxl_oracle.py), forward and data
+// gradient.  These maps are 40 % of the embedder's FLOPs and, in the generic implicit-GEMM kernels, re-read every input pixel
+// nine times from L2 with one dependent load per 32-wide K chunk.
+//
+// Here a 512-thread workgroup owns an 8 x 32 pixel tile of one map: its 10 x 34 pixel halo patch (64 channels, 128 B per pixel,
+// 144-B pitch so that the 16-B fragment reads of 16 lanes fall on 16 different bank groups) is staged ONCE in LDS, double
+// buffered -- the loads of the next tile are in flight under the MFMAs of this one.  A wave owns two tile rows (2 x 32
+// positions) and 32 of the 64 output channels; its 36 weight fragments (9 taps x 4 chunks of 16 input channels,
+// v_mfma_f32_32x32x16_bf16) stay in registers for the whole launch, the nine taps are plain offsets into the patch.  The tile
+// leaves through an fp32 C tile in LDS (two passes of 128 positions), so bias / residual are added in fp32 before the one rounding
+// to bf16 -- the same arithmetic as the generic kernel -- and every lane stores 16 contiguous bytes of an NHWC row.
+//
+// The data gradient of such a layer is the same convolution over the output gradient with the taps flipped and the channel
+// roles exchanged: the kernel reads the transposed weight pack ([Cin][tap*Cout + n]) at tap 8 - t.
+// Algorithmic HBM bytes per map pixel: 128 B read + 128 B written (+ 128 B residual); MFMA work 2 * 576 * 64 flop.
+#include "prof.h"
+#include "sdxl_ops.h"
+
+namespace tcvn {
+
+namespace {
+
+constexpr int TH = 8, TW = 32;                        // output tile
+constexpr int PW = TW + 2, PH = TH + 2;               // halo patch
+constexpr int PS = 144;                               // bytes per patch pixel (128 + 16)
+constexpr int PATCH_BYTES = PH * PW * PS;             // 48 960
+constexpr int CP = 68;                                // fp32 C tile pitch (floats)
+constexpr int CT_BYTES = 128 * CP * 4;                // 34 816
+constexpr int NCHUNK = PH * PW * 8;                   // 16-B chunks of a patch (2 720)
+constexpr int NLD = (NCHUNK + 511) / 512;             // per thread (6)
+
+struct C64Args {
+    const bf16* In; const bf16* W; const float* bias; const bf16* Res; bf16* Out;
+    int n, H, W_, flip;
+    int tiles_x, tiles_y, ntiles;
+};
+
+__global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;                                            // [2][PATCH_BYTES]
+    float* Cs = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES);  // [128][CP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wp = wave >> 1, wn = wave & 1;                       // tile rows 2wp, 2wp+1; output channels [32wn, +32)
+
+    // weight fragments: B[k][j = n]: lane (n = l31, k half = lh) holds W[32wn + n][tap'*64 + kc*16 + lh*8 .. +8]
+    bf16x8_t bw[36];
+    {
+        const bf16* wrow = g.W + (long)(32 * wn + l31) * 576 + lh * 8;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+                bw[tap * 4 + kc] = *reinterpret_cast<const bf16x8_t*>(wrow + (g.flip ? 8 - tap : tap) * 64 + kc * 16);
+    }
+    const float bias = g.bias ? g.bias[32 * wn + l31] : 0.f;
+
+    u16x8 pre[NLD];
+    auto issue = [&](int t) {
+        const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 512, pix = idx >> 3, ch = idx & 7;
+            const int py = pix / PW, px = pix - py * PW;
+            const int y = y0 + py, x = x0 + px;
+            pre[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (idx < NCHUNK && y >= 0 && y < g.H && x >= 0 && x < g.W_)
+                pre[i] = *reinterpret_cast<const u16x8*>(g.In + (((long)img * g.H + y) * g.W_ + x) * 64 + ch * 8);
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 512, pix = idx >> 3, ch = idx & 7;
+            if (idx < NCHUNK) *reinterpret_cast<u16x8*>(patch + buf * PATCH_BYTES + pix * PS + ch * 16) = pre[i];
+        }
+    };
+
+    // workgroups of one XCD (blockIdx % 8) walk neighbouring tiles, so the halo pixels two tiles share are served by one L2
+    const int nb = gridDim.x;
+    const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    int t = lb, buf = 0;
+    if (t < g.ntiles) { issue(t); commit(0); }
+    __syncthreads();
+    for (; t < g.ntiles; t += nb, buf ^= 1) {
+        const int tn = t + nb;
+        if (tn < g.ntiles) issue(tn);
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        const char* pb = patch + buf * PATCH_BYTES + ((2 * wp) * PW + l31) * PS + lh * 16;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const char* pt = pb + ((tap / 3) * PW + (tap % 3)) * PS;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(pt + kc * 32);
+                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(pt + PW * PS + kc * 32);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bw[tap * 4 + kc], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[tap * 4 + kc], acc[1], 0, 0, 0);
+            }
+        }
+        // epilogue: two passes of 128 positions (tile rows 0-3, 4-7) through the fp32 C tile
+        const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((wp >> 1) == pass) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        Cs[(((wp & 1) * 2 + rt) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + 32 * wn + l31] = acc[rt][e] + bias;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * 512, pos = idx >> 3, ch = idx & 7;     // 128 positions x 8 chunks
+                const int y = ty * TH + pass * 4 + (pos >> 5), x = tx * TW + (pos & 31);
+                if (y < g.H && x < g.W_) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + pos * CP + ch * 8);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + pos * CP + ch * 8 + 4);
+                    float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                    const long o = (((long)img * g.H + y) * g.W_ + x) * 64 + ch * 8;
+                    if (g.Res) {
+                        const u16x8 rv = *reinterpret_cast<const u16x8*>(g.Res + o);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += bf2f(rv[j]);
+                    }
+                    u16x8 ov;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ov[j] = f2bf(v[j]);
+                    *reinterpret_cast<u16x8*>(g.Out + o) = ov;
+                }
+            }
+            if (pass == 0) __syncthreads();
+        }
+        if (tn < g.ntiles) commit(buf ^ 1);
+        __syncthreads();                                          // C tile free again, next patch complete
+    }
+}
+
+constexpr size_t C64_SMEM = 2 * PATCH_BYTES + CT_BYTES;       // 132 736
+
+int launch_c64(const SConv& g, const void* In, const void* W, const float* bias, const void* Res, void* Out, int flip, hipStream_t st) {
+    C64Args a{};
+    a.In = reinterpret_cast<const bf16*>(In); a.W = reinterpret_cast<const bf16*>(W); a.bias = bias;
+    a.Res = reinterpret_cast<const bf16*>(Res); a.Out = reinterpret_cast<bf16*>(Out);
+    a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.flip = flip;
+    a.tiles_x = (g.Win + TW - 1) / TW; a.tiles_y = (g.Hin + TH - 1) / TH; a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_SMEM));
+        attr = true;
+    }
+    const int grid = a.ntiles < 256 ? a.ntiles : 256;
+    hipLaunchKernelGGL(k_sconv3_c64, dim3(grid), dim3(512), C64_SMEM, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool geom_ok(const SConv& g) {
+    return g.mode == MODE_BF16 && g.ks == 3 && g.stride == 1 && g.pad == 1 && g.Cin == 64 && g.Cout == 64 && g.lda == 64 &&
+           g.Ho == g.Hin && g.Wo == g.Win && g.Kp == 576 && g.Kpt == 576 && (long)g.n * g.Hin * g.Win < (1L << 31) / 64;
+}
+
+}  // namespace
+
+bool sconv3_c64_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, long ldres, const void* Out, long ldo, int out_f32) {
+    return geom_ok(g) && !out_f32 && ldo == 64 && (Res == nullptr || ldres == 64) && al16(In) && al16(Wk) && al16(Res) && al16(Out);
+}
+int sconv3_c64_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, hipStream_t st) {
+    return launch_c64(g, In, Wk, bias, Res, Out, 0, st);
+}
+bool sconv3_c64_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi) {
+    return geom_ok(g) && lddo == 64 && lddi == 64 && al16(dOut) && al16(Wt) && al16(dIn);
+}
+int sconv3_c64_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st) {
+    return launch_c64(g, dOut, Wt, nullptr, accumulate ? dIn : nullptr, dIn, 1, st);
+}
+
+}  // namespace tcvn

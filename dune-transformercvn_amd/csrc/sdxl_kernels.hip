@@ -573,6 +573,7 @@ int sconv_fwd(const SConv& g, const void* In, const void* Wk, const float* bias,
     char nm[96];
     ProfScope ps(label(nm, sizeof(nm), "fwd", g), 2.0 * M * g.Cout * g.ks * g.ks * g.Cin,
                  es * ((double)g.n * g.Hin * g.Win * g.Cin + M * g.Cout * (Res ? 2.0 : 1.0)), st);
+    if (sconv3_c64_fwd_ok(g, In, Wk, Res, ldres, Out, ldo, out_f32)) return sconv3_c64_fwd(g, In, Wk, bias, Res, Out, st);
     return g.mode == MODE_F32 ? fwd_t<float>(g, In, Wk, bias, Res, ldres, Out, ldo, out_f32, st)
                               : fwd_t<bf16>(g, In, Wk, bias, Res, ldres, Out, ldo, out_f32, st);
 }
@@ -583,6 +584,7 @@ int sconv_dgrad(const SConv& g, const void* dOut, long lddo, const void* Wt, voi
     char nm[96];
     ProfScope ps(label(nm, sizeof(nm), "dgrad", g), 2.0 * (double)g.n * g.Ho * g.Wo * g.Cout * g.ks * g.ks * g.Cin,
                  es * ((double)g.n * g.Ho * g.Wo * g.Cout + Mi * g.Cin), st);
+    if (sconv3_c64_dgrad_ok(g, dOut, lddo, Wt, dIn, lddi)) return sconv3_c64_dgrad(g, dOut, Wt, dIn, accumulate, st);
     return g.mode == MODE_F32 ? dgrad_t<float>(g, dOut, lddo, Wt, dIn, lddi, accumulate, st)
                               : dgrad_t<bf16>(g, dOut, lddo, Wt, dIn, lddi, accumulate, st);
 }

@@ -24,6 +24,12 @@ int sconv_dgrad(const SConv& g, const void* dOut, long lddo, const void* Wt, voi
 // dWk[n][k] += sum_m dOut[m][n] * a(m, k) (fp32, kernel layout [Cout][Kp]);  dbias[n] += sum_m dOut[m][n]
 int sconv_wgrad(const SConv& g, const void* In, const void* dOut, long lddo, float* dWk, float* dbias, hipStream_t st);
 
+// bf16 fast paths for 3x3 / stride 1 / pad 1, 64 -> 64 channels (sdxl_conv3x3.hip): halo patch in LDS, weights in registers
+bool sconv3_c64_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, long ldres, const void* Out, long ldo, int out_f32);
+int sconv3_c64_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, hipStream_t st);
+bool sconv3_c64_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi);
+int sconv3_c64_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st);
+
 // GroupNorm with ONE group (statistics over C*H*W of each image) followed by SiLU (act = 1) or nothing (act = 0).
 // stats: [n][2] doubles (sum, sum of squares), zeroed by the caller before gn_stats.
 struct GnArgs {

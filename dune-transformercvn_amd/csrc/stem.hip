@@ -401,7 +401,7 @@ int pool0_bwd_vec_grid(int n_img, int Hin, int Win) {
     return (int)(g < 2048 ? g : 2048);
 }
 bool pool0_bwd_vec_ok(const Pool0BwdArgs& a) {
-    if (a.mode == MODE_F32) return a.C == 64 && (a.e.ldg & 7) == 0 && (a.e.ldx & 7) == 0;      // tile kernel only
+    if (a.mode == MODE_F32) return conv3x3_tile_enabled() && a.C == 64 && (a.e.ldg & 7) == 0 && (a.e.ldx & 7) == 0;      // tile kernel only
     return a.mode == MODE_BF16 && (a.C == 8 || a.C == 16 || a.C == 32 || a.C == 64) && (a.e.ldg & 7) == 0 && (a.e.ldx & 7) == 0;
 }
 int pool0_bwd_vec(const Pool0BwdArgs& a, hipStream_t st) {

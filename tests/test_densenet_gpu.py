@@ -133,8 +133,8 @@ def test_densenet_backward_fp32(name, tol_max, tol_l2):
     assert not bad, bad[:8]
 
 
-def _run_bf16(cfg, sd, batch, training, d_out=None):
-    eng, data, grads = _engine(cfg, sd, mode=1, with_grad=d_out is not None)
+def _run_bf16(cfg, sd, batch, training, d_out=None, mode=1):
+    eng, data, grads = _engine(cfg, sd, mode=mode, with_grad=d_out is not None)
     n_img = int(batch[7].sum())
     out = torch.empty(n_img, eng.out_dim, device="cuda")
     eng.forward(batch[5].cuda(), batch[6].cuda(), n_img, out, train=training, seed=1)
@@ -222,6 +222,47 @@ torch.save(dict(out=out, taps=taps, grads=grads), {('/tmp/tcvn_generic_' + name 
     # layer (measured growth ~5x per layer); the drift stays far below bf16's own error (see test_densenet_bf16_*).
     print('first_launch', first_launch, 'median', median)
     assert e_out < 5e-3 and e_tap < 1e-2 and median < 5e-2 and worst < 0.5
+
+
+def test_fp32_tile_kernels_match_generic_kernels():
+    """fp32 parity mode: the MFMA tile kernels (conv3x3_f32.hip, conv1x1_f32.hip, fp32 instances of the sparse stem weight gradient
+    and the tiled pool0 backward) against the generic implicit-GEMM kernels (TCVN_DISABLE_TILE=1 on the -DTCVN_DEBUG_KNOBS build,
+    separate process).  Same fp32 products, different summation order: agreement to 1e-4 of each tensor's norm."""
+    import subprocess, sys, os
+    cfg, over, batch, g = _mid_case()
+    cfg = train_cfg(over)
+    sd = O.fill_state(cfg, int(g["weight_seed"]))
+    n_img = int(batch[7].sum())
+    d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
+    out, taps, grads = _run_bf16(cfg, sd, batch, True, d_out, mode=0)
+    code = f"""
+import sys, torch
+sys.path[:0] = {sys.path!r}
+import test_densenet_gpu as T
+from oracle import tcvn_oracle as O
+from golden_utils import train_cfg
+cfg, over, batch, g = T._mid_case()
+cfg = train_cfg(over)
+sd = O.fill_state(cfg, int(g['weight_seed']))
+n_img = int(batch[7].sum())
+d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
+out, taps, grads = T._run_bf16(cfg, sd, batch, True, d_out, mode=0)
+torch.save(dict(out=out, taps=taps, grads=grads), '/tmp/tcvn_generic_f32_mid.pt')
+"""
+    env = dict(os.environ, TCVN_DISABLE_TILE="1", TCVN_HIP_LIBRARY="libtcvn_hip_dbg.so")
+    subprocess.check_call([sys.executable, "-c", code], env=env)
+    ref = torch.load("/tmp/tcvn_generic_f32_mid.pt")
+    e_out = ((out - ref["out"]).norm() / ref["out"].norm()).item()
+    e_tap = max(((taps[k] - ref["taps"][k]).norm() / ref["taps"][k].norm()).item() for k in taps)
+    errs = []
+    for k, v in grads.items():
+        r = ref["grads"][k]
+        if r.abs().max() < 1e-6 or k.endswith(("conv0.bias", "conv1.bias", "conv2.bias", "conv.bias")):
+            continue                                   # biases in front of a BatchNorm: true gradient is zero, values are rounding noise
+        errs.append((((v - r).norm() / r.norm()).item(), k))
+    errs.sort(reverse=True)
+    print("fp32 tile vs generic: out", e_out, "taps", e_tap, "worst grads", errs[:4])
+    assert e_out < 1e-5 and e_tap < 1e-5 and errs[0][0] < 2e-4
 
 
 def test_bf16_fallback_variants_match_default_variants():
