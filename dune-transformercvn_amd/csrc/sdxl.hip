@@ -33,7 +33,7 @@ struct Bump {
 struct SLayout {
     std::vector<long> act, grad;            // per buffer (act[0] = image); grad[0] unused
     std::vector<long> wk, wkt, gwk;         // per conv
-    long stats, bstats, zero_begin, zero_end, total;
+    long stats, bstats, zero_begin, zero_end, slab, total;
 };
 }  // namespace
 
@@ -170,6 +170,7 @@ void tcvn_sdxl::layout(int n, bool bwd, SLayout& L) const {
             if (o.kind == OP_CONV) L.gwk[o.conv_id] = b.take((long)bufs[o.out].C * Kp(o) * 4);
     } else L.bstats = -1;
     L.zero_end = b.off;
+    L.slab = bwd ? b.take(kSconvSlabBytes) : -1;
     if (bwd)
         for (size_t i = 1; i < bufs.size(); ++i) L.grad[i] = b.take((long)n * bufs[i].H * bufs[i].W * bufs[i].C * esz);
     L.total = b.off;
@@ -278,7 +279,8 @@ int tcvn_sdxl::backward(int n, const float* d_out, long d_out_ld, char* ws, long
             if ((rc = gn_bwd_apply(a, dO, bufs[o.out].C, bs, ws + L.grad[o.in], bufs[o.in].C, written[o.in], st))) return rc;
             written[o.in] = 1;
         } else {
-            const SConv g = geom(o, n);
+            SConv g = geom(o, n);
+            g.slab = reinterpret_cast<float*>(ws + L.slab); g.slab_bytes = kSconvSlabBytes;
             if ((rc = sconv_wgrad(g, ws + L.act[o.in], dO, g.Cout, reinterpret_cast<float*>(ws + L.gwk[o.conv_id]), grad[o.b], st))) return rc;
             if (o.in != 0) {
                 if ((rc = sconv_dgrad(g, dO, g.Cout, ws + L.wkt[o.conv_id], ws + L.grad[o.in], g.Cin, written[o.in], st))) return rc;

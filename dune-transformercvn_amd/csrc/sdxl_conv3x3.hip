@@ -17,6 +17,7 @@
 // Algorithmic HBM bytes per map pixel: 128 B read + 128 B written (+ 128 B residual); MFMA work 2 * 576 * 64 flop.
 #include "prof.h"
 #include "sdxl_ops.h"
+#include "tcvn_ops.h"
 
 namespace tcvn {
 
@@ -25,11 +26,12 @@ namespace {
 constexpr int TH = 8, TW = 32;                        // output tile
 constexpr int PW = TW + 2, PH = TH + 2;               // halo patch
 constexpr int PS = 144;                               // bytes per patch pixel (128 + 16)
-constexpr int PATCH_BYTES = PH * PW * PS;             // 48 960
+constexpr int PATCH_BYTES = ((PH * PW + 6) / 7) * 7 * PS;    // 49 392: whole LDS-DMA groups of 7 pixels
 constexpr int CP = 68;                                // fp32 C tile pitch (floats)
 constexpr int CT_BYTES = 128 * CP * 4;                // 34 816
 constexpr int NCHUNK = PH * PW * 8;                   // 16-B chunks of a patch (2 720)
-constexpr int NLD = (NCHUNK + 511) / 512;             // per thread (6)
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_line[4];       // 16 B of zeros: LDS-DMA source of padding
 
 struct C64Args {
     const bf16* In; const bf16* W; const float* bias; const bf16* Res; bf16* Out;
@@ -57,25 +59,22 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
     }
     const float bias = g.bias ? g.bias[32 * wn + l31] : 0.f;
 
-    u16x8 pre[NLD];
-    auto issue = [&](int t) {
+    // patch staging by LDS-DMA (global_load_lds, 16 B per lane, no registers): one wave instruction writes 1 KiB of consecutive LDS,
+    // so it carries 7 pixels of 144 B -- lanes 9q .. 9q+7 the eight chunks of pixel q, lane 9q+8 the pad slot (fed from zeros),
+    // lane 63 switched off.  Pixels outside the map read the zero line as well.
+    const int dq = lane / 9, dslot = lane - dq * 9;
+    auto issue = [&](int t, int buf) {
         const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
         const int y0 = ty * TH - 1, x0 = tx * TW - 1;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * 512, pix = idx >> 3, ch = idx & 7;
+        for (int j = wave; j * 7 < PH * PW; j += 8) {
+            const int pix = j * 7 + dq;
             const int py = pix / PW, px = pix - py * PW;
             const int y = y0 + py, x = x0 + px;
-            pre[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (idx < NCHUNK && y >= 0 && y < g.H && x >= 0 && x < g.W_)
-                pre[i] = *reinterpret_cast<const u16x8*>(g.In + (((long)img * g.H + y) * g.W_ + x) * 64 + ch * 8);
-        }
-    };
-    auto commit = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * 512, pix = idx >> 3, ch = idx & 7;
-            if (idx < NCHUNK) *reinterpret_cast<u16x8*>(patch + buf * PATCH_BYTES + pix * PS + ch * 16) = pre[i];
+            const bool ok = dslot < 8 && pix < PH * PW && y >= 0 && y < g.H && x >= 0 && x < g.W_;
+            const bf16* src = ok ? g.In + (((long)img * g.H + y) * g.W_ + x) * 64 + dslot * 8 : reinterpret_cast<const bf16*>(g_zero_line);
+            if (lane < 63)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(patch + buf * PATCH_BYTES + j * 7 * PS), 16, 0, 0);
         }
     };
 
@@ -83,11 +82,12 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
     const int nb = gridDim.x;
     const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     int t = lb, buf = 0;
-    if (t < g.ntiles) { issue(t); commit(0); }
+    if (t < g.ntiles) issue(t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (; t < g.ntiles; t += nb, buf ^= 1) {
         const int tn = t + nb;
-        if (tn < g.ntiles) issue(tn);
+        if (tn < g.ntiles) issue(tn, buf ^ 1);
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
             }
             if (pass == 0) __syncthreads();
         }
-        if (tn < g.ntiles) commit(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the next patch has landed
         __syncthreads();                                          // C tile free again, next patch complete
     }
 }
@@ -163,10 +163,136 @@ int launch_c64(const SConv& g, const void* In, const void* W, const float* bias,
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient: dW[n][tap*64 + c] = sum over positions p of In[p + shift(tap)][c] * dOut[p][n].
+// The contraction runs over pixels, i.e. over the ROW index of both pixel-major LDS images, so both MFMA operands are read
+// transposed with ds_read_b64_tr_b16 (lane roles as in conv3x3_tile.hip, checked by tools/micro/tr_read_test.hip): per
+// 16-position k-step (half a tile row) a wave reads one dOut fragment and nine shifted In fragments.  A wave owns one
+// (32 c x 32 n) quarter of all nine taps for the whole launch (144 accumulator registers); the workgroup's partial
+// gradient leaves as one slab in the kernel layout [n][576], summed by k_slab_reduce.  Pixel rows are 128 B, 16-B chunks
+// XOR-swizzled with the pixel index so that the four rows of a transpose group fall on different banks.
+// Two workgroups per CU (76 KB of LDS each): one stages while the other multiplies.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4_;
+__device__ __forceinline__ bf16x8_t tr_frag_(const char* smem_base, int off_lo, int off_hi) {
+    typedef __attribute__((address_space(3))) s16x4_* lds_p;
+    const s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem_base + off_lo));
+    const s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(smem_base + off_hi));
+    struct { s16x4_ a, b; } pr = {lo, hi};
+    return __builtin_bit_cast(bf16x8_t, pr);
+}
+__device__ __forceinline__ int swz(int pix, int chunk, int sub) { return pix * 128 + ((chunk ^ (pix & 7)) << 4) + sub; }
+
+constexpr int WG_PATCH = PH * PW * 128;               // 43 520
+constexpr int WG_DOUT = TH * TW * 128;                // 32 768
+constexpr size_t WG_SMEM = WG_PATCH + WG_DOUT + 8 * 64 * 4;
+
+struct W64Args {
+    const bf16* In; const bf16* dOut; float* slab; float* bslab;
+    int n, H, W_;
+    int tiles_x, tiles_y, ntiles;
+};
+
+__global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;                                            // [PH*PW][128 B] In halo patch
+    char* dout = smem + WG_PATCH;                                  // [TH*TW][128 B] output-gradient tile
+    float* bred = reinterpret_cast<float*>(smem + WG_PATCH + WG_DOUT);      // [8][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 1, wn = wave & 1;                       // input-channel half, output-channel half
+    const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int khalf = gq >> 1, chalf = gq & 1;
+    const int a_chunk = 4 * wc + 2 * chalf + (tp >> 1), b_chunk = 4 * wn + 2 * chalf + (tp >> 1), sub = (tp & 1) * 8;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+    const int nb = gridDim.x;
+    const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    for (int t = lb; t < g.ntiles; t += nb) {
+        const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();                                           // previous tile's readers are done
+        {
+            u16x8 v[11];
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                const int idx = tid + i * 256, pix = idx >> 3, ch = idx & 7;
+                const int py = pix / PW, px = pix - py * PW;
+                const int y = y0 - 1 + py, x = x0 - 1 + px;
+                v[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (idx < NCHUNK && y >= 0 && y < g.H && x >= 0 && x < g.W_)
+                    v[i] = *reinterpret_cast<const u16x8*>(g.In + (((long)img * g.H + y) * g.W_ + x) * 64 + ch * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                const int idx = tid + i * 256, pix = idx >> 3, ch = idx & 7;
+                if (idx < NCHUNK) *reinterpret_cast<u16x8*>(patch + swz(pix, ch, 0)) = v[i];
+            }
+        }
+        {
+            u16x8 d[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + i * 256, pos = idx >> 3, ch = idx & 7;
+                const int y = y0 + (pos >> 5), x = x0 + (pos & 31);
+                d[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (y < g.H && x < g.W_) d[i] = *reinterpret_cast<const u16x8*>(g.dOut + (((long)img * g.H + y) * g.W_ + x) * 64 + ch * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + i * 256, pos = idx >> 3, ch = idx & 7;
+                *reinterpret_cast<u16x8*>(dout + swz(pos, ch, 0)) = d[i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum[j] += bf2f(d[i][j]);
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < 16; ++ks) {
+            const int ry = ks >> 1, xb = (ks & 1) * 16 + 8 * khalf + tq;           // this lane's row of the transpose group
+            const int bp = ry * TW + xb;
+            const bf16x8_t b = tr_frag_(dout, swz(bp, b_chunk, sub), swz(bp + 4, b_chunk, sub));
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ap = (ry + tap / 3) * PW + xb + tap % 3;
+                const bf16x8_t a = tr_frag_(patch, swz(ap, a_chunk, sub), swz(ap + 4, a_chunk, sub));
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    // slab[blockIdx][n][576]: accumulator row = input channel within the wave's half, column = output channel
+    {
+        const int l31 = lane & 31, lh = lane >> 5;
+        float* out = g.slab + (long)blockIdx.x * (64 * 576) + (long)(32 * wn + l31) * 576 + 32 * wc;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out[tap * 64 + (e & 3) + 8 * (e >> 2) + 4 * lh] = acc[tap][e];
+    }
+    // bias gradient: threads with equal tid & 7 hold the same 8 channels
+    __syncthreads();
+    float* br = reinterpret_cast<float*>(smem);                    // [32][64]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) br[(tid >> 3) * 64 + (tid & 7) * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+        for (int q = 0; q < 32; ++q) s += br[q * 64 + tid];
+        g.bslab[(long)blockIdx.x * 64 + tid] = s;
+    }
+    (void)bred;
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool geom_ok(const SConv& g) {
-    return g.mode == MODE_BF16 && g.ks == 3 && g.stride == 1 && g.pad == 1 && g.Cin == 64 && g.Cout == 64 && g.lda == 64 &&
+    return conv3x3_tile_enabled() && g.mode == MODE_BF16 && g.ks == 3 && g.stride == 1 && g.pad == 1 && g.Cin == 64 && g.Cout == 64 && g.lda == 64 &&
            g.Ho == g.Hin && g.Wo == g.Win && g.Kp == 576 && g.Kpt == 576 && (long)g.n * g.Hin * g.Win < (1L << 31) / 64;
 }
 
@@ -183,6 +309,30 @@ bool sconv3_c64_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void
 }
 int sconv3_c64_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st) {
     return launch_c64(g, dOut, Wt, nullptr, accumulate ? dIn : nullptr, dIn, 1, st);
+}
+
+bool sconv3_c64_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo) {
+    return geom_ok(g) && lddo == 64 && al16(In) && al16(dOut) && g.slab != nullptr &&
+           g.slab_bytes >= kSconvSlabBytes;
+}
+int sconv3_c64_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st) {
+    W64Args a{};
+    a.In = reinterpret_cast<const bf16*>(In); a.dOut = reinterpret_cast<const bf16*>(dOut);
+    a.n = g.n; a.H = g.Hin; a.W_ = g.Win;
+    a.tiles_x = (g.Win + TW - 1) / TW; a.tiles_y = (g.Hin + TH - 1) / TH; a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    const int grid = a.ntiles < 512 ? (a.ntiles < 256 ? a.ntiles : 256) : 512;
+    a.slab = g.slab; a.bslab = g.slab + (long)grid * 64 * 576;
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_sconv3_c64_wgrad, dim3(grid), dim3(256), WG_SMEM, st, a);
+    TCVN_LAUNCH_CHECK();
+    SlabJob none{};
+    SlabJob jw = slab_job(a.slab, grid, 64L * 576, dWk, 0);
+    SlabJob jb = dbias ? slab_job(a.bslab, grid, 64, dbias, 0) : none;
+    return slab_reduce2(jw, jb, st);
 }
 
 }  // namespace tcvn

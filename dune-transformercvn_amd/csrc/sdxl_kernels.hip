@@ -594,6 +594,7 @@ int sconv_wgrad(const SConv& g, const void* In, const void* dOut, long lddo, flo
     char nm[96];
     ProfScope ps(label(nm, sizeof(nm), "wgrad", g), 2.0 * M * g.Cout * g.ks * g.ks * g.Cin,
                  es * ((double)g.n * g.Hin * g.Win * g.Cin + M * g.Cout), st);
+    if (sconv3_c64_wgrad_ok(g, In, dOut, lddo)) return sconv3_c64_wgrad(g, In, dOut, dWk, dbias, st);
     return g.mode == MODE_F32 ? wgrad_t<float>(g, In, dOut, lddo, dWk, dbias, st) : wgrad_t<bf16>(g, In, dOut, lddo, dWk, dbias, st);
 }
 

@@ -15,7 +15,9 @@ struct SConv {
     int n, Hin, Win, Cin; long lda;         // input NHWC with row stride lda
     int Ho, Wo, Cout, ks, stride, pad;
     int Kp, Kpt;                            // padded K of the forward ([Cout][Kp], k = tap*Cin + c) and transposed ([Cin][Kpt], k = tap*Cout + n) packs
+    float* slab; long slab_bytes;           // optional scratch for per-workgroup partial weight gradients (sconv_wgrad fast path)
 };
+constexpr long kSconvSlabBytes = 512L * (64 * 576 + 64) * 4;     // what the 64 -> 64 weight-gradient kernel asks for
 
 int sconv_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, long ldres, void* Out, long ldo,
               int out_f32, hipStream_t st);
@@ -29,6 +31,8 @@ bool sconv3_c64_fwd_ok(const SConv& g, const void* In, const void* Wk, const voi
 int sconv3_c64_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, hipStream_t st);
 bool sconv3_c64_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi);
 int sconv3_c64_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st);
+bool sconv3_c64_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo);
+int sconv3_c64_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st);
 
 // GroupNorm with ONE group (statistics over C*H*W of each image) followed by SiLU (act = 1) or nothing (act = 0).
 // stats: [n][2] doubles (sum, sum of squares), zeroed by the caller before gn_stats.

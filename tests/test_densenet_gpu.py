@@ -227,7 +227,7 @@ torch.save(dict(out=out, taps=taps, grads=grads), {('/tmp/tcvn_generic_' + name 
 def test_fp32_tile_kernels_match_generic_kernels():
     """fp32 parity mode: the MFMA tile kernels (conv3x3_f32.hip, conv1x1_f32.hip, fp32 instances of the sparse stem weight gradient
     and the tiled pool0 backward) against the generic implicit-GEMM kernels (TCVN_DISABLE_TILE=1 on the -DTCVN_DEBUG_KNOBS build,
-    separate process).  Same fp32 products, different summation order: agreement to 1e-4 of each tensor's norm."""
+    separate process).  Same fp32 products, different summation order: forward to 1e-5, gradients to 1e-3 of each tensor's norm (the fp32 noise floor of this net, see test_densenet_backward_fp32)."""
     import subprocess, sys, os
     cfg, over, batch, g = _mid_case()
     cfg = train_cfg(over)
@@ -262,7 +262,7 @@ torch.save(dict(out=out, taps=taps, grads=grads), '/tmp/tcvn_generic_f32_mid.pt'
         errs.append((((v - r).norm() / r.norm()).item(), k))
     errs.sort(reverse=True)
     print("fp32 tile vs generic: out", e_out, "taps", e_tap, "worst grads", errs[:4])
-    assert e_out < 1e-5 and e_tap < 1e-5 and errs[0][0] < 2e-4
+    assert e_out < 1e-5 and e_tap < 1e-5 and errs[0][0] < 1e-3
 
 
 def test_bf16_fallback_variants_match_default_variants():

@@ -81,6 +81,54 @@ def test_sdxl_embedder_forward_backward_vs_oracle(mode, tol, gtol):
     assert not bad, bad[:8]
 
 
+def _run_wide(mode_env=None):
+    """Width-64 embedder on two 264 x 280 maps (bf16): taps of the 64-channel stages and every gradient."""
+    cfg = _cfg(initial_pixel_dim=64, pixel_embedding_dim=512, pixel_shape=(264, 280))
+    sd = O.fill_state(cfg, 13)
+    batch = O.synthetic_batch([1], 6, cfg)
+    n_img = int(batch[7].sum())
+    d_out = torch.randn(n_img, 512, generator=torch.Generator().manual_seed(4))
+    eng, data, grads = _engine(cfg, sd, 1, True)
+    out = torch.empty(n_img, 512, device="cuda")
+    eng.forward(batch[5].cuda(), batch[6].cuda(), n_img, out, train=True, seed=1)
+    taps = {t: eng.tap(t).float().cpu() for t in ("conv_in", "block0", "block1", "block2")}
+    eng.backward(d_out.cuda())
+    torch.cuda.synchronize()
+    return cfg, sd, batch, d_out, out.cpu(), taps, {k: v.cpu() for k, v in grads.items()}
+
+
+def test_sdxl_c64_tile_kernels_vs_generic_and_oracle():
+    """The 64 -> 64 halo-patch kernels (sdxl_conv3x3.hip: forward, data gradient, weight gradient) at the production width on maps
+    that are not multiples of the 8 x 32 tile: against the generic implicit-GEMM kernels (TCVN_DISABLE_TILE=1 on the debug build,
+    separate process; same bf16 products, other summation order) and against the fp64 oracle within the bf16 band of the
+    small-width test above."""
+    import os, subprocess, sys
+    cfg, sd, batch, d_out, out, taps, grads = _run_wide()
+    code = f"""
+import sys, torch
+sys.path[:0] = {sys.path!r}
+import test_sdxl_gpu as T
+cfg, sd, batch, d_out, out, taps, grads = T._run_wide()
+torch.save(dict(out=out, taps=taps, grads=grads), '/tmp/tcvn_sdxl_generic.pt')
+"""
+    env = dict(os.environ, TCVN_DISABLE_TILE="1", TCVN_HIP_LIBRARY="libtcvn_hip_dbg.so")
+    subprocess.check_call([sys.executable, "-c", code], env=env)
+    ref = torch.load("/tmp/tcvn_sdxl_generic.pt")
+    e_taps = {k: ((taps[k] - ref["taps"][k]).norm() / ref["taps"][k].norm()).item() for k in taps}
+    e_out = ((out - ref["out"]).norm() / ref["out"].norm()).item()
+    e_grads = sorted(((((grads[k] - ref["grads"][k]).norm() / ref["grads"][k].norm().clamp_min(1e-30)).item(), k)
+                      for k in grads if ref["grads"][k].abs().max() > 0), reverse=True)
+    print("sdxl c64 tile vs generic: taps", e_taps, "out", e_out, "worst grads", e_grads[:4])
+    assert max(e_taps.values()) < 1e-2 and e_out < 2e-2 and e_grads[0][0] < 5e-2
+    o_ref, o_taps, g_ref = _oracle(cfg, sd, batch, d_out, dtype=torch.float32)
+    e_o = ((out.double() - o_ref.double()).norm() / o_ref.double().norm()).item()
+    e_b0 = ((taps["block0"].permute(0, 3, 1, 2).double() - o_taps[PFX + ":block0"].double()).norm() / o_taps[PFX + ":block0"].double().norm()).item()
+    worst = max(((grads[k].double().reshape(r.shape) - r.double()).norm() / r.double().norm().clamp_min(1e-30)).item()
+                for k, r in g_ref.items() if "to_q" not in k and "to_k" not in k)
+    print("sdxl c64 vs fp32 oracle: out", e_o, "block0", e_b0, "worst grad", worst)
+    assert e_o < 3e-2 and e_b0 < 3e-2 and worst < 8e-2
+
+
 def test_sdxl_full_model_train_step_vs_oracle():
     cfg = _cfg()
     sd = O.fill_state(cfg, 7)
