@@ -47,6 +47,7 @@ struct tcvn_sdxl {
     int n_conv = 0, n_gn = 0;
     bool bound = false;
     int last_n = 0;
+    const int32_t* last_coords = nullptr; long last_nnz = 0;       // COO list of the last forward (conv_in weight gradient)
     char* d_desc = nullptr; size_t desc_cap = 0; char* desc_ws = nullptr; long desc_total = 0; int n_pack = 0;
     char* d_undesc = nullptr; char* undesc_ws = nullptr; long undesc_total = 0; int n_unpack = 0;
     std::vector<char> h_desc, h_undesc;
@@ -233,7 +234,7 @@ int tcvn_sdxl::forward(int n, const int32_t* coords, const float* values, long n
                                 o.res >= 0 ? bufs[o.res].C : 0, dst, ldo, o.final_f32, st))) return rc;
         }
     }
-    last_n = n;
+    last_n = n; last_coords = coords; last_nnz = nnz;
     return 0;
 }
 
@@ -281,6 +282,7 @@ int tcvn_sdxl::backward(int n, const float* d_out, long d_out_ld, char* ws, long
         } else {
             SConv g = geom(o, n);
             g.slab = reinterpret_cast<float*>(ws + L.slab); g.slab_bytes = kSconvSlabBytes;
+            if (o.in == 0) { g.hits = last_coords; g.nnz = last_nnz; }
             if ((rc = sconv_wgrad(g, ws + L.act[o.in], dO, g.Cout, reinterpret_cast<float*>(ws + L.gwk[o.conv_id]), grad[o.b], st))) return rc;
             if (o.in != 0) {
                 if ((rc = sconv_dgrad(g, dO, g.Cout, ws + L.wkt[o.conv_id], ws + L.grad[o.in], g.Cin, written[o.in], st))) return rc;

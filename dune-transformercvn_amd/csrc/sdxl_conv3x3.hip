@@ -31,6 +31,9 @@ constexpr int CP = 68;                                // fp32 C tile pitch (floa
 constexpr int CT_BYTES = 128 * CP * 4;                // 34 816
 constexpr int NCHUNK = PH * PW * 8;                   // 16-B chunks of a patch (2 720)
 
+// barrier that orders LDS traffic only: __syncthreads() would also wait for every outstanding global store (vmcnt(0))
+__device__ __forceinline__ void lds_barrier_() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __attribute__((aligned(16))) unsigned int g_zero_line[4];       // 16 B of zeros: LDS-DMA source of padding
 
 struct C64Args {
@@ -105,6 +108,9 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[tap * 4 + kc], acc[1], 0, 0, 0);
             }
         }
+        // the next patch was requested before the MFMAs: collect it here, in front of the epilogue, so that the epilogue's global
+        // stores (which retire through the same in-order vmcnt) drain under the next tile instead of being waited for
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // epilogue: two passes of 128 positions (tile rows 0-3, 4-7) through the fp32 C tile
         const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
 #pragma unroll
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
                     for (int e = 0; e < 16; ++e)
                         Cs[(((wp & 1) * 2 + rt) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + 32 * wn + l31] = acc[rt][e] + bias;
             }
-            __syncthreads();
+            lds_barrier_();
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int idx = tid + i * 512, pos = idx >> 3, ch = idx & 7;     // 128 positions x 8 chunks
@@ -137,14 +143,163 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
                     *reinterpret_cast<u16x8*>(g.Out + o) = ov;
                 }
             }
-            if (pass == 0) __syncthreads();
+            if (pass == 0) lds_barrier_();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the next patch has landed
-        __syncthreads();                                          // C tile free again, next patch complete
+        lds_barrier_();                                          // C tile free again, next patch complete
     }
 }
 
 constexpr size_t C64_SMEM = 2 * PATCH_BYTES + CT_BYTES;       // 132 736
+
+// ---------------------------------------------------------------------------------------------------------------------
+// General width (input and output channels multiples of 64; the 128 / 256 / 512-channel stages): same tile, same patch, but the
+// input channels pass through LDS in chunks of 64 and a workgroup produces one group of 64 output channels (blockIdx.y).
+// The weight fragments no longer fit in registers, so they stream from L2 one tap ahead of the MFMAs in a ring of five slots
+// (tap t lives in slot t % 5; the loads of tap t+2 are issued under tap t).  vmcnt retires in order, so the LDS-DMA of the next
+// patch is issued only after the last fragment loads of the chunk (and the first two taps of the next chunk) are in flight:
+// nothing the MFMAs wait for is queued behind an HBM access.
+// ---------------------------------------------------------------------------------------------------------------------
+struct CGArgs {
+    const bf16* In; const bf16* W; const float* bias; const bf16* Res; bf16* Out;
+    int n, H, W_, flip;
+    int cin, cout, nc;                                  // channels of this pass' input / output, cin / 64
+    int tiles_x, tiles_y, ntiles;
+};
+
+__global__ __launch_bounds__(512, 1) void k_sconv3_g(const CGArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;
+    float* Cs = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wp = wave >> 1, wn = wave & 1;
+    const int n0 = 64 * blockIdx.y;                                // this workgroup's output channels [n0, n0 + 64)
+    const bf16* wrow = g.W + (long)(n0 + 32 * wn + l31) * (9 * g.cin) + lh * 8;
+    const float bias = g.bias ? g.bias[n0 + 32 * wn + l31] : 0.f;
+
+    bf16x8_t bq[5][4];
+#define TCVN_BLOAD(slot, chunk, tap)                                                                              \
+    {                                                                                                             \
+        const bf16* p_ = wrow + (g.flip ? 8 - (tap) : (tap)) * g.cin + (chunk) * 64;                              \
+        _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) bq[slot][kc] = *reinterpret_cast<const bf16x8_t*>(p_ + kc * 16); \
+    }
+    const int dq = lane / 9, dslot = lane - dq * 9;
+    auto issue = [&](int t, int chunk, int buf) {
+        const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+        for (int j = wave; j * 7 < PH * PW; j += 8) {
+            const int pix = j * 7 + dq;
+            const int py = pix / PW, px = pix - py * PW;
+            const int y = y0 + py, x = x0 + px;
+            const bool ok = dslot < 8 && pix < PH * PW && y >= 0 && y < g.H && x >= 0 && x < g.W_;
+            const bf16* src = ok ? g.In + (((long)img * g.H + y) * g.W_ + x) * g.cin + chunk * 64 + dslot * 8
+                                 : reinterpret_cast<const bf16*>(g_zero_line);
+            if (lane < 63)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(patch + buf * PATCH_BYTES + j * 7 * PS), 16, 0, 0);
+        }
+    };
+
+    const int nb = gridDim.x;
+    const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    int t = lb, chunk = 0, buf = 0;
+    if (t >= g.ntiles) return;
+    issue(t, 0, 0);
+    TCVN_BLOAD(0, 0, 0)
+    TCVN_BLOAD(1, 0, 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    while (true) {
+        int nchunk = chunk + 1, nt = t;
+        if (nchunk == g.nc) { nchunk = 0; nt = t + nb; }
+        const bool more = nt < g.ntiles;
+        const char* pb = patch + buf * PATCH_BYTES + ((2 * wp) * PW + l31) * PS + lh * 16;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap <= 6) TCVN_BLOAD((tap + 2) % 5, chunk, tap + 2)
+            if (tap == 6 && more) TCVN_BLOAD(0, nchunk, 0)
+            if (tap == 7 && more) {
+                TCVN_BLOAD(1, nchunk, 1)
+                issue(nt, nchunk, buf ^ 1);
+            }
+            const char* pt = pb + ((tap / 3) * PW + (tap % 3)) * PS;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(pt + kc * 32);
+                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(pt + PW * PS + kc * 32);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[tap % 5][kc], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[tap % 5][kc], acc[1], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // next patch + next fragments; in front of the epilogue's stores
+        if (chunk == g.nc - 1) {
+            const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                if ((wp >> 1) == pass) {
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            Cs[(((wp & 1) * 2 + rt) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + 32 * wn + l31] = acc[rt][e] + bias;
+                }
+                lds_barrier_();
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = tid + i * 512, pos = idx >> 3, ch = idx & 7;
+                    const int y = ty * TH + pass * 4 + (pos >> 5), x = tx * TW + (pos & 31);
+                    if (y < g.H && x < g.W_) {
+                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + pos * CP + ch * 8);
+                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + pos * CP + ch * 8 + 4);
+                        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                        const long o = (((long)img * g.H + y) * g.W_ + x) * g.cout + n0 + ch * 8;
+                        if (g.Res) {
+                            const u16x8 rv = *reinterpret_cast<const u16x8*>(g.Res + o);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += bf2f(rv[j]);
+                        }
+                        u16x8 ov;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ov[j] = f2bf(v[j]);
+                        *reinterpret_cast<u16x8*>(g.Out + o) = ov;
+                    }
+                }
+                if (pass == 0) lds_barrier_();
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        }
+        lds_barrier_();
+        if (!more) break;
+        t = nt; chunk = nchunk; buf ^= 1;
+    }
+#undef TCVN_BLOAD
+}
+
+int launch_g(const SConv& g, const void* In, int cin, const void* W, int cout, const float* bias, const void* Res, void* Out, int flip,
+             hipStream_t st) {
+    CGArgs a{};
+    a.In = reinterpret_cast<const bf16*>(In); a.W = reinterpret_cast<const bf16*>(W); a.bias = bias;
+    a.Res = reinterpret_cast<const bf16*>(Res); a.Out = reinterpret_cast<bf16*>(Out);
+    a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.flip = flip; a.cin = cin; a.cout = cout; a.nc = cin / 64;
+    a.tiles_x = (g.Win + TW - 1) / TW; a.tiles_y = (g.Hin + TH - 1) / TH; a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_SMEM));
+        attr = true;
+    }
+    const int grid = a.ntiles < 256 ? a.ntiles : 256;
+    hipLaunchKernelGGL(k_sconv3_g, dim3(grid, cout / 64), dim3(512), C64_SMEM, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
 
 int launch_c64(const SConv& g, const void* In, const void* W, const float* bias, const void* Res, void* Out, int flip, hipStream_t st) {
     C64Args a{};
@@ -191,6 +346,7 @@ struct W64Args {
     const bf16* In; const bf16* dOut; float* slab; float* bslab;
     int n, H, W_;
     int tiles_x, tiles_y, ntiles;
+    int cin, cout;                        // row strides; blockIdx.y selects the (64 c) x (64 n) sub-block: c chunk fastest
 };
 
 __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
@@ -212,6 +368,8 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
 
+    const int ncc = g.cin >> 6;
+    const int c0 = 64 * (blockIdx.y % ncc), n0 = 64 * (blockIdx.y / ncc);
     const int nb = gridDim.x;
     const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     for (int t = lb; t < g.ntiles; t += nb) {
@@ -227,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
                 const int y = y0 - 1 + py, x = x0 - 1 + px;
                 v[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 if (idx < NCHUNK && y >= 0 && y < g.H && x >= 0 && x < g.W_)
-                    v[i] = *reinterpret_cast<const u16x8*>(g.In + (((long)img * g.H + y) * g.W_ + x) * 64 + ch * 8);
+                    v[i] = *reinterpret_cast<const u16x8*>(g.In + (((long)img * g.H + y) * g.W_ + x) * g.cin + c0 + ch * 8);
             }
 #pragma unroll
             for (int i = 0; i < 11; ++i) {
@@ -242,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
                 const int idx = tid + i * 256, pos = idx >> 3, ch = idx & 7;
                 const int y = y0 + (pos >> 5), x = x0 + (pos & 31);
                 d[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (y < g.H && x < g.W_) d[i] = *reinterpret_cast<const u16x8*>(g.dOut + (((long)img * g.H + y) * g.W_ + x) * 64 + ch * 8);
+                if (y < g.H && x < g.W_) d[i] = *reinterpret_cast<const u16x8*>(g.dOut + (((long)img * g.H + y) * g.W_ + x) * g.cout + n0 + ch * 8);
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -269,12 +427,13 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
     // slab[blockIdx][n][576]: accumulator row = input channel within the wave's half, column = output channel
     {
         const int l31 = lane & 31, lh = lane >> 5;
-        float* out = g.slab + (long)blockIdx.x * (64 * 576) + (long)(32 * wn + l31) * 576 + 32 * wc;
+        float* out = g.slab + ((long)blockIdx.x * gridDim.y + blockIdx.y) * (64 * 576) + (long)(32 * wn + l31) * 576 + 32 * wc;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
             for (int e = 0; e < 16; ++e) out[tap * 64 + (e & 3) + 8 * (e >> 2) + 4 * lh] = acc[tap][e];
     }
+    if (g.bslab == nullptr) return;                                // uniform: general width takes the bias gradient from a column sum
     // bias gradient: threads with equal tid & 7 hold the same 8 channels
     __syncthreads();
     float* br = reinterpret_cast<float*>(smem);                    // [32][64]
@@ -298,6 +457,26 @@ bool geom_ok(const SConv& g) {
 
 }  // namespace
 
+namespace {
+bool geom_g_ok(const SConv& g) {
+    return conv3x3_tile_enabled() && g.mode == MODE_BF16 && g.ks == 3 && g.stride == 1 && g.pad == 1 && g.Cin % 64 == 0 && g.Cout % 64 == 0 &&
+           g.Cin <= 512 && g.Cout <= 512 && g.lda == g.Cin && g.Ho == g.Hin && g.Wo == g.Win && g.Kp == 9 * g.Cin && g.Kpt == 9 * g.Cout &&
+           !(g.Cin == 64 && g.Cout == 64);
+}
+}  // namespace
+bool sconv3_g_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, long ldres, const void* Out, long ldo, int out_f32) {
+    return geom_g_ok(g) && !out_f32 && ldo == g.Cout && (Res == nullptr || ldres == g.Cout) && al16(In) && al16(Wk) && al16(Res) && al16(Out);
+}
+int sconv3_g_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, hipStream_t st) {
+    return launch_g(g, In, g.Cin, Wk, g.Cout, bias, Res, Out, 0, st);
+}
+bool sconv3_g_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi) {
+    return geom_g_ok(g) && lddo == g.Cout && lddi == g.Cin && al16(dOut) && al16(Wt) && al16(dIn);
+}
+int sconv3_g_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st) {
+    return launch_g(g, dOut, g.Cout, Wt, g.Cin, nullptr, accumulate ? dIn : nullptr, dIn, 1, st);
+}
+
 bool sconv3_c64_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, long ldres, const void* Out, long ldo, int out_f32) {
     return geom_ok(g) && !out_f32 && ldo == 64 && (Res == nullptr || ldres == 64) && al16(In) && al16(Wk) && al16(Res) && al16(Out);
 }
@@ -311,6 +490,78 @@ int sconv3_c64_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn
     return launch_c64(g, dOut, Wt, nullptr, accumulate ? dIn : nullptr, dIn, 1, st);
 }
 
+namespace {
+// dWk[(n0 + n)*Kp + tap*Cin + c0 + c] += sum_x slab[x][sub][n][tap*64 + c]
+__global__ __launch_bounds__(256) void k_sub_reduce(const float* __restrict__ slab, int nx, int nsub, int ncc, int cin, float* __restrict__ dWk) {
+    const int sub = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;                  // element of the 64 x 576 sub-block
+    if (i >= 64 * 576) return;
+    float s0 = 0.f, s1 = 0.f;
+    int x = 0;
+    for (; x + 1 < nx; x += 2) {
+        s0 += slab[((long)x * nsub + sub) * (64 * 576) + i];
+        s1 += slab[((long)(x + 1) * nsub + sub) * (64 * 576) + i];
+    }
+    if (x < nx) s0 += slab[((long)x * nsub + sub) * (64 * 576) + i];
+    const int n = i / 576, k = i - n * 576, tap = k >> 6, c = k & 63;
+    const int c0 = 64 * (sub % ncc), n0 = 64 * (sub / ncc);
+    dWk[(long)(n0 + n) * (9 * cin) + tap * cin + c0 + c] += s0 + s1;
+}
+// dst[c] += column sums of X [rows][C] bf16, C/8 divides 256
+__global__ __launch_bounds__(256) void k_colsum_bf16(const bf16* __restrict__ X, long rows, int C, float* __restrict__ dst) {
+    extern __shared__ float cred[];                                // [256 / (C/8)][C]
+    const int c8 = C >> 3, lanes = 256 / c8;
+    const int cg = threadIdx.x % c8, rl = threadIdx.x / c8;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long r = (long)blockIdx.x * lanes + rl; r < rows; r += (long)gridDim.x * lanes) {
+        const u16x8 v = *reinterpret_cast<const u16x8*>(X + r * C + cg * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += bf2f(v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cred[rl * C + cg * 8 + j] = s[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = 0.f;
+        for (int q = 0; q < lanes; ++q) t += cred[q * C + c];
+        atomicAdd(dst + c, t);
+    }
+}
+}  // namespace
+
+bool sconv3_g_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo) {
+    return geom_g_ok(g) && lddo == g.Cout && al16(In) && al16(dOut) && g.slab != nullptr && g.slab_bytes >= kSconvSlabBytes;
+}
+int sconv3_g_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st) {
+    W64Args a{};
+    a.In = reinterpret_cast<const bf16*>(In); a.dOut = reinterpret_cast<const bf16*>(dOut);
+    a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.cin = g.Cin; a.cout = g.Cout;
+    a.tiles_x = (g.Win + TW - 1) / TW; a.tiles_y = (g.Hin + TH - 1) / TH; a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    const int ncc = g.Cin / 64, nsub = ncc * (g.Cout / 64);
+    int gx = 512 / nsub;                                           // slab holds 512 sub-block partials; two workgroups per CU
+    if (gx > a.ntiles) gx = a.ntiles;
+    if (gx < 1) gx = 1;
+    a.slab = g.slab; a.bslab = nullptr;
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_sconv3_c64_wgrad, dim3(gx, nsub), dim3(256), WG_SMEM, st, a);
+    TCVN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sub_reduce, dim3((64 * 576 + 255) / 256, nsub), dim3(256), 0, st, a.slab, gx, nsub, ncc, g.Cin, dWk);
+    TCVN_LAUNCH_CHECK();
+    if (dbias != nullptr) {
+        const long rows = (long)g.n * g.Hin * g.Win;
+        const int lanes = 256 / (g.Cout / 8);
+        long nb = (rows + lanes * 16 - 1) / (lanes * 16);
+        if (nb > 512) nb = 512;
+        hipLaunchKernelGGL(k_colsum_bf16, dim3((int)nb), dim3(256), (size_t)lanes * g.Cout * 4, st, reinterpret_cast<const bf16*>(dOut), rows, g.Cout, dbias);
+        TCVN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 bool sconv3_c64_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo) {
     return geom_ok(g) && lddo == 64 && al16(In) && al16(dOut) && g.slab != nullptr &&
            g.slab_bytes >= kSconvSlabBytes;
@@ -318,7 +569,7 @@ bool sconv3_c64_wgrad_ok(const SConv& g, const void* In, const void* dOut, long 
 int sconv3_c64_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st) {
     W64Args a{};
     a.In = reinterpret_cast<const bf16*>(In); a.dOut = reinterpret_cast<const bf16*>(dOut);
-    a.n = g.n; a.H = g.Hin; a.W_ = g.Win;
+    a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.cin = 64; a.cout = 64;
     a.tiles_x = (g.Win + TW - 1) / TW; a.tiles_y = (g.Hin + TH - 1) / TH; a.ntiles = g.n * a.tiles_x * a.tiles_y;
     const int grid = a.ntiles < 512 ? (a.ntiles < 256 ? a.ntiles : 256) : 512;
     a.slab = g.slab; a.bslab = g.slab + (long)grid * 64 * 576;

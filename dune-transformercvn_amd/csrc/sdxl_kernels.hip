@@ -497,6 +497,132 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const GnArgs a, const T* _
     }
 }
 
+// ---- dense-row vector variants (ldx == ldo == C, C % 8 == 0, HW*C < 2^31): 16 B per lane, no divisions, gamma/beta from LDS ----
+template <typename T> __device__ __forceinline__ void store8g(T* p, const float v[8]);
+template <> __device__ __forceinline__ void store8g<float>(float* p, const float v[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void store8g<bf16>(bf16* p, const float v[8]) {
+    u16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(v[j]);
+    *reinterpret_cast<u16x8*>(p) = o;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_act_v(const GnArgs a, T* __restrict__ Out) {
+    extern __shared__ __attribute__((aligned(16))) float gb[];          // [2][C]
+    for (int c = threadIdx.x; c < 2 * a.C; c += 256) gb[c] = c < a.C ? a.gamma[c] : a.beta[c - a.C];
+    __syncthreads();
+    const int img = blockIdx.y;
+    float mean, rstd;
+    gn_mean_rstd(a.stats, img, (double)a.HW * a.C, a.eps, mean, rstd);
+    const int per8 = a.HW * a.C / 8, stride = gridDim.x * 256;
+    const T* X = reinterpret_cast<const T*>(a.X) + (long)img * a.HW * a.C;
+    T* O = Out + (long)img * a.HW * a.C;
+    int o = blockIdx.x * 256 + threadIdx.x;
+    int c = (int)(((long)o * 8) % a.C);
+    const int cstep = (int)(((long)stride * 8) % a.C);
+    for (; o < per8; o += stride) {
+        float v[8];
+        load8<T>(X + (long)o * 8, v);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gb + c), g1 = *reinterpret_cast<const f32x4*>(gb + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(gb + a.C + c), b1 = *reinterpret_cast<const f32x4*>(gb + a.C + c + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float u = (v[j] - mean) * rstd * (j < 4 ? g0[j & 3] : g1[j & 3]) + (j < 4 ? b0[j & 3] : b1[j & 3]);
+            v[j] = a.act ? silu(u) : u;
+        }
+        store8g<T>(O + (long)o * 8, v);
+        c += cstep; if (c >= a.C) c -= a.C;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_bwd_apply_v(const GnArgs a, const T* __restrict__ dA, const double* bsum, T* __restrict__ dX,
+                                                        int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float gb[];          // [2][C]
+    for (int c = threadIdx.x; c < 2 * a.C; c += 256) gb[c] = c < a.C ? a.gamma[c] : a.beta[c - a.C];
+    __syncthreads();
+    const int img = blockIdx.y;
+    float mean, rstd;
+    const double cnt = (double)a.HW * a.C;
+    gn_mean_rstd(a.stats, img, cnt, a.eps, mean, rstd);
+    const float c1 = (float)(bsum[img * 2] / cnt), c2 = (float)(bsum[img * 2 + 1] / cnt);
+    const int per8 = a.HW * a.C / 8, stride = gridDim.x * 256;
+    const long base = (long)img * a.HW * a.C;
+    const T* X = reinterpret_cast<const T*>(a.X) + base;
+    int o = blockIdx.x * 256 + threadIdx.x;
+    int c = (int)(((long)o * 8) % a.C);
+    const int cstep = (int)(((long)stride * 8) % a.C);
+    for (; o < per8; o += stride) {
+        float x[8], d[8], acc8[8];
+        load8<T>(X + (long)o * 8, x);
+        load8<T>(dA + base + (long)o * 8, d);
+        if (accumulate) load8<T>(dX + base + (long)o * 8, acc8);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gb + c), g1 = *reinterpret_cast<const f32x4*>(gb + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(gb + a.C + c), b1 = *reinterpret_cast<const f32x4*>(gb + a.C + c + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gmm = j < 4 ? g0[j & 3] : g1[j & 3], bt = j < 4 ? b0[j & 3] : b1[j & 3];
+            const float xh = (x[j] - mean) * rstd;
+            const float u = xh * gmm + bt;
+            const float du = d[j] * (a.act ? dsilu(u) : 1.f);
+            const float dx = rstd * (gmm * du - c1 - xh * c2);
+            x[j] = accumulate ? acc8[j] + dx : dx;
+        }
+        store8g<T>(dX + base + (long)o * 8, x);
+        c += cstep; if (c >= a.C) c -= a.C;
+    }
+}
+
+// reduce: C/8 channel groups x 256/(C/8) pixel lanes per workgroup (C in {64, 128, 256, 512}: C/8 divides 256); a thread keeps its
+// 8 channels for all its pixels, so dgamma / dbeta partial sums live in registers
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_bwd_reduce_v(const GnArgs a, const T* __restrict__ dA, double* bsum, float* dgamma, float* dbeta,
+                                                         int rows) {
+    __shared__ double red[4][2];
+    extern __shared__ __attribute__((aligned(16))) float chs[];         // [2][C]
+    const int img = blockIdx.y;
+    float mean, rstd;
+    gn_mean_rstd(a.stats, img, (double)a.HW * a.C, a.eps, mean, rstd);
+    for (int c = threadIdx.x; c < 2 * a.C; c += 256) chs[c] = 0.f;
+    __syncthreads();
+    const int c8 = a.C >> 3, lanes = 256 / c8;
+    const int c = (threadIdx.x % c8) * 8, pl = threadIdx.x / c8;
+    float gmm[8], bt[8], dg[8], db[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gmm[j] = a.gamma[c + j]; bt[j] = a.beta[c + j]; dg[j] = 0.f; db[j] = 0.f; }
+    const long base = (long)img * a.HW * a.C;
+    const T* X = reinterpret_cast<const T*>(a.X) + base;
+    float f1 = 0.f, f2 = 0.f;
+    double s1 = 0, s2 = 0;
+    int k = 0;
+    (void)rows;                                                         // pixels are dealt round-robin over the (few) workgroups of an image
+    for (int px = blockIdx.x * lanes + pl; px < a.HW; px += gridDim.x * lanes) {
+        float x[8], d[8];
+        load8<T>(X + (long)px * a.C + c, x);
+        load8<T>(dA + base + (long)px * a.C + c, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (x[j] - mean) * rstd;
+            const float u = xh * gmm[j] + bt[j];
+            const float du = d[j] * (a.act ? dsilu(u) : 1.f);
+            dg[j] += du * xh; db[j] += du;
+            f1 += gmm[j] * du; f2 += gmm[j] * du * xh;
+        }
+        if (++k == 8) { s1 += f1; s2 += f2; f1 = 0.f; f2 = 0.f; k = 0; }       // short fp32 runs, fp64 across them
+    }
+    s1 += f1; s2 += f2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { atomicAdd(&chs[c + j], dg[j]); atomicAdd(&chs[a.C + c + j], db[j]); }
+    block_sum2(s1, s2, red);
+    if (threadIdx.x == 0) { atomicAdd(bsum + img * 2, s1); atomicAdd(bsum + img * 2 + 1, s2); }
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < a.C; cc += 256) { atomicAdd(dgamma + cc, chs[cc]); atomicAdd(dbeta + cc, chs[a.C + cc]); }
+}
+
 template <typename T>
 __global__ void k_cast_f32_to(const float* src, long lds, T* dst, long ldd, long rows, int cols) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -574,6 +700,8 @@ int sconv_fwd(const SConv& g, const void* In, const void* Wk, const float* bias,
     ProfScope ps(label(nm, sizeof(nm), "fwd", g), 2.0 * M * g.Cout * g.ks * g.ks * g.Cin,
                  es * ((double)g.n * g.Hin * g.Win * g.Cin + M * g.Cout * (Res ? 2.0 : 1.0)), st);
     if (sconv3_c64_fwd_ok(g, In, Wk, Res, ldres, Out, ldo, out_f32)) return sconv3_c64_fwd(g, In, Wk, bias, Res, Out, st);
+    if (sconv_in_fwd_ok(g, In, Wk, Res, Out, ldo, out_f32)) return sconv_in_fwd(g, In, Wk, bias, Out, st);
+    if (sconv3_g_fwd_ok(g, In, Wk, Res, ldres, Out, ldo, out_f32)) return sconv3_g_fwd(g, In, Wk, bias, Res, Out, st);
     return g.mode == MODE_F32 ? fwd_t<float>(g, In, Wk, bias, Res, ldres, Out, ldo, out_f32, st)
                               : fwd_t<bf16>(g, In, Wk, bias, Res, ldres, Out, ldo, out_f32, st);
 }
@@ -585,6 +713,7 @@ int sconv_dgrad(const SConv& g, const void* dOut, long lddo, const void* Wt, voi
     ProfScope ps(label(nm, sizeof(nm), "dgrad", g), 2.0 * (double)g.n * g.Ho * g.Wo * g.Cout * g.ks * g.ks * g.Cin,
                  es * ((double)g.n * g.Ho * g.Wo * g.Cout + Mi * g.Cin), st);
     if (sconv3_c64_dgrad_ok(g, dOut, lddo, Wt, dIn, lddi)) return sconv3_c64_dgrad(g, dOut, Wt, dIn, accumulate, st);
+    if (sconv3_g_dgrad_ok(g, dOut, lddo, Wt, dIn, lddi)) return sconv3_g_dgrad(g, dOut, Wt, dIn, accumulate, st);
     return g.mode == MODE_F32 ? dgrad_t<float>(g, dOut, lddo, Wt, dIn, lddi, accumulate, st)
                               : dgrad_t<bf16>(g, dOut, lddo, Wt, dIn, lddi, accumulate, st);
 }
@@ -595,8 +724,17 @@ int sconv_wgrad(const SConv& g, const void* In, const void* dOut, long lddo, flo
     ProfScope ps(label(nm, sizeof(nm), "wgrad", g), 2.0 * M * g.Cout * g.ks * g.ks * g.Cin,
                  es * ((double)g.n * g.Hin * g.Win * g.Cin + M * g.Cout), st);
     if (sconv3_c64_wgrad_ok(g, In, dOut, lddo)) return sconv3_c64_wgrad(g, In, dOut, dWk, dbias, st);
+    if (sconv_in_wgrad_ok(g, dOut, lddo)) return sconv_in_wgrad(g, In, dOut, dWk, dbias, st);
+    if (sconv3_g_wgrad_ok(g, In, dOut, lddo)) return sconv3_g_wgrad(g, In, dOut, dWk, dbias, st);
     return g.mode == MODE_F32 ? wgrad_t<float>(g, In, dOut, lddo, dWk, dbias, st) : wgrad_t<bf16>(g, In, dOut, lddo, dWk, dbias, st);
 }
+
+namespace {
+// dense rows, whole 16-B groups, 32-bit element indices within an image
+bool gn_dense(const GnArgs& a) {
+    return (a.C & 7) == 0 && a.ldx == a.C && (long)a.HW * a.C < (1L << 31) && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
+}
+}  // namespace
 
 int gn_stats(const GnArgs& a, hipStream_t st) {
     if (a.n <= 0) return 0;
@@ -612,6 +750,13 @@ int gn_act(const GnArgs& a, void* Out, long ldo, hipStream_t st) {
     int gx = cdiv(per / 8 + 1, 256);
     if (gx > 2048) gx = 2048;
     const dim3 grid(gx, a.n);
+    if (gn_dense(a) && ldo == a.C) {
+        const size_t smem = 2 * (size_t)a.C * sizeof(float);
+        if (a.mode == MODE_F32) hipLaunchKernelGGL(k_gn_act_v<float>, grid, dim3(256), smem, st, a, reinterpret_cast<float*>(Out));
+        else hipLaunchKernelGGL(k_gn_act_v<bf16>, grid, dim3(256), smem, st, a, reinterpret_cast<bf16*>(Out));
+        TCVN_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.mode == MODE_F32) hipLaunchKernelGGL(k_gn_act<float>, grid, dim3(256), 0, st, a, reinterpret_cast<float*>(Out), ldo);
     else hipLaunchKernelGGL(k_gn_act<bf16>, grid, dim3(256), 0, st, a, reinterpret_cast<bf16*>(Out), ldo);
     TCVN_LAUNCH_CHECK();
@@ -623,6 +768,19 @@ int gn_bwd_reduce(const GnArgs& a, const void* dA, long ldda, double* bsum, floa
     if (rows < 1) rows = 1;
     const dim3 grid(cdiv(a.HW, rows), a.n);
     const size_t smem = 2 * (size_t)a.C * sizeof(float);
+    if (gn_dense(a) && ldda == a.C && 256 % (a.C / 8) == 0) {
+        // few workgroups per image: every workgroup ends with 2C global atomics on the same dgamma / dbeta words
+        int gxv = cdiv(a.HW, 4096);
+        const int cap = a.n >= 64 ? 8 : a.n >= 8 ? 32 : 128;
+        if (gxv > cap) gxv = cap;
+        const dim3 grid(gxv, a.n);
+        if (a.mode == MODE_F32)
+            hipLaunchKernelGGL(k_gn_bwd_reduce_v<float>, grid, dim3(256), smem, st, a, reinterpret_cast<const float*>(dA), bsum, dgamma, dbeta, rows);
+        else
+            hipLaunchKernelGGL(k_gn_bwd_reduce_v<bf16>, grid, dim3(256), smem, st, a, reinterpret_cast<const bf16*>(dA), bsum, dgamma, dbeta, rows);
+        TCVN_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.mode == MODE_F32)
         hipLaunchKernelGGL(k_gn_bwd_reduce<float>, grid, dim3(256), smem, st, a, reinterpret_cast<const float*>(dA), ldda, bsum, dgamma, dbeta, rows);
     else
@@ -637,6 +795,18 @@ int gn_bwd_apply(const GnArgs& a, const void* dA, long ldda, const double* bsum,
     if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
     const dim3 grid(gx, a.n);
+    if (gn_dense(a) && ldda == a.C && lddx == a.C) {
+        int gv = cdiv(per / 8, 256 * 2);
+        if (gv > 2048) gv = 2048;
+        if (gv < 1) gv = 1;
+        const size_t smem = 2 * (size_t)a.C * sizeof(float);
+        if (a.mode == MODE_F32)
+            hipLaunchKernelGGL(k_gn_bwd_apply_v<float>, dim3(gv, a.n), dim3(256), smem, st, a, reinterpret_cast<const float*>(dA), bsum, reinterpret_cast<float*>(dX), accumulate);
+        else
+            hipLaunchKernelGGL(k_gn_bwd_apply_v<bf16>, dim3(gv, a.n), dim3(256), smem, st, a, reinterpret_cast<const bf16*>(dA), bsum, reinterpret_cast<bf16*>(dX), accumulate);
+        TCVN_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.mode == MODE_F32)
         hipLaunchKernelGGL(k_gn_bwd_apply<float>, grid, dim3(256), 0, st, a, reinterpret_cast<const float*>(dA), ldda, bsum, reinterpret_cast<float*>(dX), lddx, accumulate);
     else

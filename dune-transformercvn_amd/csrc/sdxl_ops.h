@@ -16,6 +16,7 @@ struct SConv {
     int Ho, Wo, Cout, ks, stride, pad;
     int Kp, Kpt;                            // padded K of the forward ([Cout][Kp], k = tap*Cin + c) and transposed ([Cin][Kpt], k = tap*Cout + n) packs
     float* slab; long slab_bytes;           // optional scratch for per-workgroup partial weight gradients (sconv_wgrad fast path)
+    const int* hits; long nnz;              // optional: COO list (image, y, x) of the non-zero input pixels (conv_in weight gradient)
 };
 constexpr long kSconvSlabBytes = 512L * (64 * 576 + 64) * 4;     // what the 64 -> 64 weight-gradient kernel asks for
 
@@ -31,6 +32,18 @@ bool sconv3_c64_fwd_ok(const SConv& g, const void* In, const void* Wk, const voi
 int sconv3_c64_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, hipStream_t st);
 bool sconv3_c64_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi);
 int sconv3_c64_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st);
+// general width (channels multiples of 64, <= 512): chunked patch, weight fragments streamed from L2
+bool sconv3_g_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, long ldres, const void* Out, long ldo, int out_f32);
+int sconv3_g_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, hipStream_t st);
+bool sconv3_g_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi);
+int sconv3_g_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st);
+bool sconv3_g_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo);
+int sconv3_g_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st);
+// conv_in (3 -> 64, sdxl_stem.hip): gather-MFMA forward, weight gradient from the hit list
+bool sconv_in_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, const void* Out, long ldo, int out_f32);
+int sconv_in_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, hipStream_t st);
+bool sconv_in_wgrad_ok(const SConv& g, const void* dOut, long lddo);
+int sconv_in_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st);
 bool sconv3_c64_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo);
 int sconv3_c64_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st);
 
