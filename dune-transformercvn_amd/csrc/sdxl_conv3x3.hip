@@ -36,6 +36,15 @@ __device__ __forceinline__ void lds_barrier_() { asm volatile("s_waitcnt lgkmcnt
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_line[4];       // 16 B of zeros: LDS-DMA source of padding
 
+#ifdef TCVN_PHASE_PROF
+__device__ unsigned long long g_ph2[16];
+#define PH2_INIT long long ph_last = clock64();
+#define PH2(i) if (threadIdx.x == 0) { const long long ph_now = clock64(); atomicAdd(&g_ph2[i], (unsigned long long)(ph_now - ph_last)); ph_last = ph_now; }
+#else
+#define PH2_INIT
+#define PH2(i)
+#endif
+
 struct C64Args {
     const bf16* In; const bf16* W; const float* bias; const bf16* Res; bf16* Out;
     int n, H, W_, flip;
@@ -88,9 +97,12 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
     if (t < g.ntiles) issue(t, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    PH2_INIT
     for (; t < g.ntiles; t += nb, buf ^= 1) {
         const int tn = t + nb;
+        PH2(4)
         if (tn < g.ntiles) issue(tn, buf ^ 1);
+        PH2(0)
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -108,9 +120,11 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[tap * 4 + kc], acc[1], 0, 0, 0);
             }
         }
+        PH2(1)
         // the next patch was requested before the MFMAs: collect it here, in front of the epilogue, so that the epilogue's global
         // stores (which retire through the same in-order vmcnt) drain under the next tile instead of being waited for
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PH2(2)
         // epilogue: two passes of 128 positions (tile rows 0-3, 4-7) through the fp32 C tile
         const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
 #pragma unroll
@@ -145,6 +159,7 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
             }
             if (pass == 0) lds_barrier_();
         }
+        PH2(3)
         lds_barrier_();                                          // C tile free again, next patch complete
     }
 }
@@ -587,3 +602,10 @@ int sconv3_c64_wgrad(const SConv& g, const void* In, const void* dOut, float* dW
 }
 
 }  // namespace tcvn
+
+#ifdef TCVN_PHASE_PROF
+extern "C" int tcvn_debug_phases2(unsigned long long* out16) {
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(tcvn::g_ph2), 16 * 8);
+    return 0;
+}
+#endif
