@@ -600,30 +600,19 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce_v(const GnArgs a, const T
     double s1 = 0, s2 = 0;
     int k = 0;
     (void)rows;                                                         // pixels are dealt round-robin over the (few) workgroups of an image
-    const int pstep = gridDim.x * lanes;
-    for (int px = blockIdx.x * lanes + pl; px < a.HW; px += 4 * pstep) {          // four pixels per trip: eight 16-B loads in flight
-        float x[4][8], d[4][8];
+    for (int px = blockIdx.x * lanes + pl; px < a.HW; px += gridDim.x * lanes) {
+        float x[8], d[8];
+        load8<T>(X + (long)px * a.C + c, x);
+        load8<T>(dA + base + (long)px * a.C + c, d);
 #pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
-            const int p = px + u4 * pstep;
-            if (p < a.HW) { load8<T>(X + (long)p * a.C + c, x[u4]); load8<T>(dA + base + (long)p * a.C + c, d[u4]); }
-            else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { x[u4][j] = 0.f; d[u4][j] = 0.f; }
-            }
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (x[j] - mean) * rstd;
+            const float u = xh * gmm[j] + bt[j];
+            const float du = d[j] * (a.act ? dsilu(u) : 1.f);
+            dg[j] += du * xh; db[j] += du;
+            f1 += gmm[j] * du; f2 += gmm[j] * du * xh;
         }
-#pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = (x[u4][j] - mean) * rstd;
-                const float u = xh * gmm[j] + bt[j];
-                const float du = d[u4][j] * (a.act ? dsilu(u) : 1.f);            // d == 0 beyond the image: contributes nothing
-                dg[j] += du * xh; db[j] += du;
-                f1 += gmm[j] * du; f2 += gmm[j] * du * xh;
-            }
-        }
-        if (++k == 2) { s1 += f1; s2 += f2; f1 = 0.f; f2 = 0.f; k = 0; }       // short fp32 runs, fp64 across them
+        if (++k == 8) { s1 += f1; s2 += f2; f1 = 0.f; f2 = 0.f; k = 0; }       // short fp32 runs, fp64 across them
     }
     s1 += f1; s2 += f2;
 #pragma unroll
