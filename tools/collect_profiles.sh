@@ -12,6 +12,8 @@ echo "[collect] default bench"; timeout -k 10 500 python3 $ROOT/bench.py > $OUT/
 tail -c 600 $OUT/bench_default.json; echo
 echo "[collect] bf16 kernel trace"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/bf16 -o bf16 --output-format csv -- python3 $ROOT/bench.py --precision bf16 --steps 4 --warmup 1 --no-cpu-baseline --no-fp32 > $OUT/bf16_bench_under_rocprof.json 2> $OUT/bf16.err || exit 2
+echo "[collect] bf16 kernel trace, weight-gradient side stream off (per-kernel durations without sharing)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/bf16_serial -o bf16_serial --output-format csv -- python3 $ROOT/bench.py --precision bf16 --steps 4 --warmup 1 --no-cpu-baseline --no-fp32 --no-bwd-overlap > $OUT/bf16_serial_bench_under_rocprof.json 2> $OUT/bf16_serial.err || exit 2
 echo "[collect] fp32 kernel trace"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/fp32 -o fp32 --output-format csv -- python3 $ROOT/bench.py --precision fp32 --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $OUT/fp32_bench_under_rocprof.json 2> $OUT/fp32.err || exit 3
 echo "[collect] sdxl kernel trace"
