@@ -298,6 +298,223 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_g(const CGArgs g) {
 #undef TCVN_BLOAD
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-2 down-sampler forward (3x3, pad 0, zeros beyond the map; channels multiples of 64): the general-width scheme on a
+// 2 x 32 output tile -- its 5 x 65 input patch has the size of the stride-1 patch -- with four waves (tile row x channel half),
+// input pixel = 2 * output pixel + tap.  Input-bound: four input pixels are read per output pixel.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int S2_PH = 5, S2_PW = 65;                  // patch of a 2 x 32 output tile
+constexpr size_t S2_SMEM = 2 * PATCH_BYTES + 64 * CP * 4;
+
+struct S2Args {
+    const bf16* In; const bf16* W; const float* bias; bf16* Out;
+    int n, Hi, Wi, Ho, Wo, cin, cout, nc;
+    int tiles_x, tiles_y, ntiles;
+};
+
+__global__ __launch_bounds__(256, 1) void k_sconv3_s2_fwd(const S2Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;
+    float* Cs = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 1, wn = wave & 1;                       // output tile row, channel half
+    const int n0 = 64 * blockIdx.y;
+    const bf16* wrow = g.W + (long)(n0 + 32 * wn + l31) * (9 * g.cin) + lh * 8;
+    const float bias = g.bias ? g.bias[n0 + 32 * wn + l31] : 0.f;
+    bf16x8_t bq[5][4];
+#define TCVN_BLOAD(slot, chunk, tap)                                                                              \
+    {                                                                                                             \
+        const bf16* p_ = wrow + (tap) * g.cin + (chunk) * 64;                                                     \
+        _Pragma("unroll") for (int kc = 0; kc < 4; ++kc) bq[slot][kc] = *reinterpret_cast<const bf16x8_t*>(p_ + kc * 16); \
+    }
+    const int dq = lane / 9, dslot = lane - dq * 9;
+    auto issue = [&](int t, int chunk, int buf) {
+        const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
+        const int y0 = 2 * (ty * 2), x0 = 2 * (tx * TW);
+        for (int j = wave; j * 7 < S2_PH * S2_PW; j += 4) {
+            const int pix = j * 7 + dq;
+            const int py = pix / S2_PW, px = pix - py * S2_PW;
+            const int y = y0 + py, x = x0 + px;
+            const bool ok = dslot < 8 && pix < S2_PH * S2_PW && y < g.Hi && x < g.Wi;
+            const bf16* src = ok ? g.In + (((long)img * g.Hi + y) * g.Wi + x) * g.cin + chunk * 64 + dslot * 8
+                                 : reinterpret_cast<const bf16*>(g_zero_line);
+            if (lane < 63)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(patch + buf * PATCH_BYTES + j * 7 * PS), 16, 0, 0);
+        }
+    };
+    const int nb = gridDim.x;
+    const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    int t = lb, chunk = 0, buf = 0;
+    if (t >= g.ntiles) return;
+    issue(t, 0, 0);
+    TCVN_BLOAD(0, 0, 0)
+    TCVN_BLOAD(1, 0, 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    while (true) {
+        int nchunk = chunk + 1, nt = t;
+        if (nchunk == g.nc) { nchunk = 0; nt = t + nb; }
+        const bool more = nt < g.ntiles;
+        const char* pb = patch + buf * PATCH_BYTES + ((2 * wr) * S2_PW + 2 * l31) * PS + lh * 16;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap <= 6) TCVN_BLOAD((tap + 2) % 5, chunk, tap + 2)
+            if (tap == 6 && more) TCVN_BLOAD(0, nchunk, 0)
+            if (tap == 7 && more) {
+                TCVN_BLOAD(1, nchunk, 1)
+                issue(nt, nchunk, buf ^ 1);
+            }
+            const char* pt = pb + ((tap / 3) * S2_PW + (tap % 3)) * PS;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(pt + kc * 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[tap % 5][kc], acc, 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (chunk == g.nc - 1) {
+            const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Cs[(wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + 32 * wn + l31] = acc[e] + bias;
+            lds_barrier_();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * 256, pos = idx >> 3, ch = idx & 7;     // 64 positions x 8 chunks
+                const int y = ty * 2 + (pos >> 5), x = tx * TW + (pos & 31);
+                if (y < g.Ho && x < g.Wo) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + pos * CP + ch * 8);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + pos * CP + ch * 8 + 4);
+                    u16x8 ov;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ov[j] = f2bf(c0[j]); ov[4 + j] = f2bf(c1[j]); }
+                    *reinterpret_cast<u16x8*>(g.Out + (((long)img * g.Ho + y) * g.Wo + x) * g.cout + n0 + ch * 8) = ov;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        }
+        lds_barrier_();
+        if (!more) break;
+        t = nt; chunk = nchunk; buf ^= 1;
+    }
+#undef TCVN_BLOAD
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-2 down-sampler data gradient, 64 output-gradient channels (the two full-resolution down-samplers):
+//   dIn[y][x][c] = sum over taps with (y - ky), (x - kx) even of dOut[(y - ky)/2][(x - kx)/2][n] * W[n][c][ky][kx].
+// The input pixels fall into four parity classes (y & 1, x & 1) with 4 / 2 / 2 / 1 contributing taps; each class is a small
+// stride-1 convolution over the half-resolution output gradient.  A workgroup owns 4 x 32 half-resolution positions (8 x 64 input
+// pixels): the 5 x 33 dOut patch arrives by LDS-DMA (double buffered), the 36 weight fragments of the transposed pack stay in
+// registers, and the four classes are multiplied one after the other through the fp32 C tile (16-B stores of every other pixel).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int D2_PH = 5, D2_PW = 33;
+constexpr int D2_PATCH = ((D2_PH * D2_PW + 6) / 7) * 7 * PS;          // 24 192
+constexpr size_t D2_SMEM = 2 * D2_PATCH + CT_BYTES;
+
+struct D2Args {
+    const bf16* dOut; const bf16* Wt; bf16* dIn;
+    int n, Hi, Wi, Ho, Wo, cin, accumulate;
+    int tiles_x, tiles_y, ntiles;
+};
+
+__global__ __launch_bounds__(512, 1) void k_sconv3_s2_dgrad(const D2Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;
+    float* Cs = reinterpret_cast<float*>(smem + 2 * D2_PATCH);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wy = wave >> 1, wn = wave & 1;
+    const int n0 = 64 * blockIdx.y;                                // this workgroup's input channels [n0, n0 + 64)
+    bf16x8_t bw[36];
+    {
+        const bf16* wrow = g.Wt + (long)(n0 + 32 * wn + l31) * 576 + lh * 8;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) bw[tap * 4 + kc] = *reinterpret_cast<const bf16x8_t*>(wrow + tap * 64 + kc * 16);
+    }
+    const int dq = lane / 9, dslot = lane - dq * 9;
+    auto issue = [&](int t, int buf) {
+        const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
+        const int y0 = ty * 4 - 1, x0 = tx * TW - 1;
+        for (int j = wave; j * 7 < D2_PH * D2_PW; j += 8) {
+            const int pix = j * 7 + dq;
+            const int py = pix / D2_PW, px = pix - py * D2_PW;
+            const int y = y0 + py, x = x0 + px;
+            const bool ok = dslot < 8 && pix < D2_PH * D2_PW && y >= 0 && y < g.Ho && x >= 0 && x < g.Wo;
+            const bf16* src = ok ? g.dOut + (((long)img * g.Ho + y) * g.Wo + x) * 64 + dslot * 8 : reinterpret_cast<const bf16*>(g_zero_line);
+            if (lane < 63)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(patch + buf * D2_PATCH + j * 7 * PS), 16, 0, 0);
+        }
+    };
+    const int nb = gridDim.x;
+    const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    int t = lb, buf = 0;
+    if (t < g.ntiles) issue(t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (; t < g.ntiles; t += nb, buf ^= 1) {
+        const int tn = t + nb;
+        if (tn < g.ntiles) issue(tn, buf ^ 1);
+        const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
+        const char* pb = patch + buf * D2_PATCH + lh * 16;
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                if ((ky & 1) != py) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    if ((kx & 1) != px) continue;
+                    const char* pt = pb + ((wy + (ky == 2 ? 0 : 1)) * D2_PW + l31 + (kx == 2 ? 0 : 1)) * PS;
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) {
+                        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(pt + kc * 32);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[(ky * 3 + kx) * 4 + kc], acc, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Cs[(wy * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + 32 * wn + l31] = acc[e];
+            lds_barrier_();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * 512, pos = idx >> 3, ch = idx & 7;     // 128 half-resolution positions x 8 chunks
+                const int y = 2 * (ty * 4 + (pos >> 5)) + py, x = 2 * (tx * TW + (pos & 31)) + px;
+                if (y < g.Hi && x < g.Wi) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + pos * CP + ch * 8);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + pos * CP + ch * 8 + 4);
+                    float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                    bf16* o = g.dIn + (((long)img * g.Hi + y) * g.Wi + x) * g.cin + n0 + ch * 8;
+                    if (g.accumulate) {
+                        const u16x8 rv = *reinterpret_cast<const u16x8*>(o);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += bf2f(rv[j]);
+                    }
+                    u16x8 ov;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ov[j] = f2bf(v[j]);
+                    *reinterpret_cast<u16x8*>(o) = ov;
+                }
+            }
+            lds_barrier_();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // next patch (the stores of this tile with it: once per tile)
+        lds_barrier_();
+    }
+}
+
 int launch_g(const SConv& g, const void* In, int cin, const void* W, int cout, const float* bias, const void* Res, void* Out, int flip,
              hipStream_t st) {
     CGArgs a{};
@@ -355,21 +572,29 @@ __device__ __forceinline__ int swz(int pix, int chunk, int sub) { return pix * 1
 
 constexpr int WG_PATCH = PH * PW * 128;               // 43 520
 constexpr int WG_DOUT = TH * TW * 128;                // 32 768
-constexpr size_t WG_SMEM = WG_PATCH + WG_DOUT + 8 * 64 * 4;
+constexpr size_t WG_SMEM = WG_PATCH + WG_DOUT;                      // stride 1; the stride-2 instance needs less
 
 struct W64Args {
     const bf16* In; const bf16* dOut; float* slab; float* bslab;
-    int n, H, W_;
+    int n, H, W_;                         // output map (= the dOut tensor)
     int tiles_x, tiles_y, ntiles;
     int cin, cout;                        // row strides; blockIdx.y selects the (64 c) x (64 n) sub-block: c chunk fastest
+    int Hi, Wi;                           // input map
 };
 
+// S = 1: 3x3 / stride 1 / pad 1 (8 x 32 output tile, 10 x 34 patch); S = 2: 3x3 / stride 2 / pad 0 with zeros beyond the map
+// (diffusers' F.pad(0,1,0,1) down-sampler: 2 x 32 output tile, 5 x 65 patch, input pixel = 2 * output pixel + tap)
+template <int S>
 __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
+    constexpr int OTH = S == 1 ? 8 : 2;                            // output tile rows
+    constexpr int PHs = S * OTH + (S == 1 ? 2 : 1), PWs = S * TW + (S == 1 ? 2 : 1), ORG = S == 1 ? 1 : 0;
+    constexpr int NPC = PHs * PWs * 8, NPL = (NPC + 255) / 256;    // patch chunks, per thread
+    constexpr int NDL = OTH * TW * 8 / 256;                        // dOut chunks per thread
+    constexpr int PATCH_B = PHs * PWs * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;                                            // [PH*PW][128 B] In halo patch
-    char* dout = smem + WG_PATCH;                                  // [TH*TW][128 B] output-gradient tile
-    float* bred = reinterpret_cast<float*>(smem + WG_PATCH + WG_DOUT);      // [8][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* dout = smem + PATCH_B;                                  // [TH*TW][128 B] output-gradient tile
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 1, wn = wave & 1;                       // input-channel half, output-channel half
     const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
     const int khalf = gq >> 1, chalf = gq & 1;
@@ -389,36 +614,36 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
     const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     for (int t = lb; t < g.ntiles; t += nb) {
         const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
-        const int y0 = ty * TH, x0 = tx * TW;
+        const int y0 = ty * OTH, x0 = tx * TW;
         __syncthreads();                                           // previous tile's readers are done
         {
-            u16x8 v[11];
+            u16x8 v[NPL];
 #pragma unroll
-            for (int i = 0; i < 11; ++i) {
+            for (int i = 0; i < NPL; ++i) {
                 const int idx = tid + i * 256, pix = idx >> 3, ch = idx & 7;
-                const int py = pix / PW, px = pix - py * PW;
-                const int y = y0 - 1 + py, x = x0 - 1 + px;
+                const int py = pix / PWs, px = pix - py * PWs;
+                const int y = S * y0 - ORG + py, x = S * x0 - ORG + px;
                 v[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (idx < NCHUNK && y >= 0 && y < g.H && x >= 0 && x < g.W_)
-                    v[i] = *reinterpret_cast<const u16x8*>(g.In + (((long)img * g.H + y) * g.W_ + x) * g.cin + c0 + ch * 8);
+                if (idx < NPC && y >= 0 && y < g.Hi && x >= 0 && x < g.Wi)
+                    v[i] = *reinterpret_cast<const u16x8*>(g.In + (((long)img * g.Hi + y) * g.Wi + x) * g.cin + c0 + ch * 8);
             }
 #pragma unroll
-            for (int i = 0; i < 11; ++i) {
+            for (int i = 0; i < NPL; ++i) {
                 const int idx = tid + i * 256, pix = idx >> 3, ch = idx & 7;
-                if (idx < NCHUNK) *reinterpret_cast<u16x8*>(patch + swz(pix, ch, 0)) = v[i];
+                if (idx < NPC) *reinterpret_cast<u16x8*>(patch + swz(pix, ch, 0)) = v[i];
             }
         }
         {
-            u16x8 d[8];
+            u16x8 d[NDL];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NDL; ++i) {
                 const int idx = tid + i * 256, pos = idx >> 3, ch = idx & 7;
                 const int y = y0 + (pos >> 5), x = x0 + (pos & 31);
                 d[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 if (y < g.H && x < g.W_) d[i] = *reinterpret_cast<const u16x8*>(g.dOut + (((long)img * g.H + y) * g.W_ + x) * g.cout + n0 + ch * 8);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NDL; ++i) {
                 const int idx = tid + i * 256, pos = idx >> 3, ch = idx & 7;
                 *reinterpret_cast<u16x8*>(dout + swz(pos, ch, 0)) = d[i];
 #pragma unroll
@@ -427,14 +652,14 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
         }
         __syncthreads();
 #pragma unroll 2
-        for (int ks = 0; ks < 16; ++ks) {
+        for (int ks = 0; ks < OTH * TW / 16; ++ks) {
             const int ry = ks >> 1, xb = (ks & 1) * 16 + 8 * khalf + tq;           // this lane's row of the transpose group
             const int bp = ry * TW + xb;
             const bf16x8_t b = tr_frag_(dout, swz(bp, b_chunk, sub), swz(bp + 4, b_chunk, sub));
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const int ap = (ry + tap / 3) * PW + xb + tap % 3;
-                const bf16x8_t a = tr_frag_(patch, swz(ap, a_chunk, sub), swz(ap + 4, a_chunk, sub));
+                const int ap = (S * ry + tap / 3) * PWs + S * xb + tap % 3;
+                const bf16x8_t a = tr_frag_(patch, swz(ap, a_chunk, sub), swz(ap + 4 * S, a_chunk, sub));
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
             }
         }
@@ -460,7 +685,6 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
         for (int q = 0; q < 32; ++q) s += br[q * 64 + tid];
         g.bslab[(long)blockIdx.x * 64 + tid] = s;
     }
-    (void)bred;
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -550,7 +774,7 @@ bool sconv3_g_wgrad_ok(const SConv& g, const void* In, const void* dOut, long ld
 int sconv3_g_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st) {
     W64Args a{};
     a.In = reinterpret_cast<const bf16*>(In); a.dOut = reinterpret_cast<const bf16*>(dOut);
-    a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.cin = g.Cin; a.cout = g.Cout;
+    a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.cin = g.Cin; a.cout = g.Cout; a.Hi = g.Hin; a.Wi = g.Win;
     a.tiles_x = (g.Win + TW - 1) / TW; a.tiles_y = (g.Hin + TH - 1) / TH; a.ntiles = g.n * a.tiles_x * a.tiles_y;
     const int ncc = g.Cin / 64, nsub = ncc * (g.Cout / 64);
     int gx = 512 / nsub;                                           // slab holds 512 sub-block partials; two workgroups per CU
@@ -559,15 +783,88 @@ int sconv3_g_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk,
     a.slab = g.slab; a.bslab = nullptr;
     static bool attr = false;
     if (!attr) {
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
         attr = true;
     }
-    hipLaunchKernelGGL(k_sconv3_c64_wgrad, dim3(gx, nsub), dim3(256), WG_SMEM, st, a);
+    hipLaunchKernelGGL(k_sconv3_c64_wgrad<1>, dim3(gx, nsub), dim3(256), WG_SMEM, st, a);
     TCVN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sub_reduce, dim3((64 * 576 + 255) / 256, nsub), dim3(256), 0, st, a.slab, gx, nsub, ncc, g.Cin, dWk);
     TCVN_LAUNCH_CHECK();
     if (dbias != nullptr) {
         const long rows = (long)g.n * g.Hin * g.Win;
+        const int lanes = 256 / (g.Cout / 8);
+        long nb = (rows + lanes * 16 - 1) / (lanes * 16);
+        if (nb > 512) nb = 512;
+        hipLaunchKernelGGL(k_colsum_bf16, dim3((int)nb), dim3(256), (size_t)lanes * g.Cout * 4, st, reinterpret_cast<const bf16*>(dOut), rows, g.Cout, dbias);
+        TCVN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+namespace {
+bool geom_s2_ok(const SConv& g) {
+    return conv3x3_tile_enabled() && g.mode == MODE_BF16 && g.ks == 3 && g.stride == 2 && g.pad == 0 && g.Cin % 64 == 0 && g.Cout % 64 == 0 &&
+           g.Cin <= 512 && g.Cout <= 512 && g.lda == g.Cin && g.Ho == (g.Hin - 2) / 2 + 1 && g.Wo == (g.Win - 2) / 2 + 1 &&
+           g.Kp == 9 * g.Cin && g.Kpt == 9 * g.Cout;
+}
+}  // namespace
+bool sconv3_s2_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, const void* Out, long ldo, int out_f32) {
+    return geom_s2_ok(g) && Res == nullptr && !out_f32 && ldo == g.Cout && al16(In) && al16(Wk) && al16(Out);
+}
+int sconv3_s2_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, hipStream_t st) {
+    S2Args a{};
+    a.In = reinterpret_cast<const bf16*>(In); a.W = reinterpret_cast<const bf16*>(Wk); a.bias = bias; a.Out = reinterpret_cast<bf16*>(Out);
+    a.n = g.n; a.Hi = g.Hin; a.Wi = g.Win; a.Ho = g.Ho; a.Wo = g.Wo; a.cin = g.Cin; a.cout = g.Cout; a.nc = g.Cin / 64;
+    a.tiles_x = (g.Wo + TW - 1) / TW; a.tiles_y = (g.Ho + 1) / 2; a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_s2_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S2_SMEM));
+        attr = true;
+    }
+    const int grid = a.ntiles < 256 ? a.ntiles : 256;
+    hipLaunchKernelGGL(k_sconv3_s2_fwd, dim3(grid, g.Cout / 64), dim3(256), S2_SMEM, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+bool sconv3_s2_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi) {
+    return geom_s2_ok(g) && g.Cout == 64 && lddo == 64 && lddi == g.Cin && al16(dOut) && al16(Wt) && al16(dIn);
+}
+int sconv3_s2_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st) {
+    D2Args a{};
+    a.dOut = reinterpret_cast<const bf16*>(dOut); a.Wt = reinterpret_cast<const bf16*>(Wt); a.dIn = reinterpret_cast<bf16*>(dIn);
+    a.n = g.n; a.Hi = g.Hin; a.Wi = g.Win; a.Ho = g.Ho; a.Wo = g.Wo; a.cin = g.Cin; a.accumulate = accumulate;
+    // half-resolution positions (Y, X) cover input pixels (2Y + py, 2X + px): Y up to ceil(Hi / 2) - 1
+    const int hy = (g.Hin + 1) / 2, hx = (g.Win + 1) / 2;
+    a.tiles_x = (hx + TW - 1) / TW; a.tiles_y = (hy + 3) / 4; a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_s2_dgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)D2_SMEM));
+        attr = true;
+    }
+    const int grid = a.ntiles < 256 ? a.ntiles : 256;
+    hipLaunchKernelGGL(k_sconv3_s2_dgrad, dim3(grid, g.Cin / 64), dim3(512), D2_SMEM, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+bool sconv3_s2_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo) {
+    return geom_s2_ok(g) && lddo == g.Cout && al16(In) && al16(dOut) && g.slab != nullptr && g.slab_bytes >= kSconvSlabBytes;
+}
+int sconv3_s2_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st) {
+    W64Args a{};
+    a.In = reinterpret_cast<const bf16*>(In); a.dOut = reinterpret_cast<const bf16*>(dOut);
+    a.n = g.n; a.H = g.Ho; a.W_ = g.Wo; a.Hi = g.Hin; a.Wi = g.Win; a.cin = g.Cin; a.cout = g.Cout;
+    a.tiles_x = (g.Wo + TW - 1) / TW; a.tiles_y = (g.Ho + 1) / 2; a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    const int ncc = g.Cin / 64, nsub = ncc * (g.Cout / 64);
+    int gx = 512 / nsub;
+    if (gx > a.ntiles) gx = a.ntiles;
+    if (gx < 1) gx = 1;
+    a.slab = g.slab; a.bslab = nullptr;
+    hipLaunchKernelGGL(k_sconv3_c64_wgrad<2>, dim3(gx, nsub), dim3(256), (size_t)(5 * 65 * 128 + 2 * TW * 128), st, a);
+    TCVN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sub_reduce, dim3((64 * 576 + 255) / 256, nsub), dim3(256), 0, st, a.slab, gx, nsub, ncc, g.Cin, dWk);
+    TCVN_LAUNCH_CHECK();
+    if (dbias != nullptr) {
+        const long rows = (long)g.n * g.Ho * g.Wo;
         const int lanes = 256 / (g.Cout / 8);
         long nb = (rows + lanes * 16 - 1) / (lanes * 16);
         if (nb > 512) nb = 512;
@@ -584,16 +881,16 @@ bool sconv3_c64_wgrad_ok(const SConv& g, const void* In, const void* dOut, long 
 int sconv3_c64_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st) {
     W64Args a{};
     a.In = reinterpret_cast<const bf16*>(In); a.dOut = reinterpret_cast<const bf16*>(dOut);
-    a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.cin = 64; a.cout = 64;
+    a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.cin = 64; a.cout = 64; a.Hi = g.Hin; a.Wi = g.Win;
     a.tiles_x = (g.Win + TW - 1) / TW; a.tiles_y = (g.Hin + TH - 1) / TH; a.ntiles = g.n * a.tiles_x * a.tiles_y;
     const int grid = a.ntiles < 512 ? (a.ntiles < 256 ? a.ntiles : 256) : 512;
     a.slab = g.slab; a.bslab = g.slab + (long)grid * 64 * 576;
     static bool attr = false;
     if (!attr) {
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
         attr = true;
     }
-    hipLaunchKernelGGL(k_sconv3_c64_wgrad, dim3(grid), dim3(256), WG_SMEM, st, a);
+    hipLaunchKernelGGL(k_sconv3_c64_wgrad<1>, dim3(grid), dim3(256), WG_SMEM, st, a);
     TCVN_LAUNCH_CHECK();
     SlabJob none{};
     SlabJob jw = slab_job(a.slab, grid, 64L * 576, dWk, 0);

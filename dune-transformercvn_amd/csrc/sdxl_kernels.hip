@@ -702,6 +702,7 @@ int sconv_fwd(const SConv& g, const void* In, const void* Wk, const float* bias,
     if (sconv3_c64_fwd_ok(g, In, Wk, Res, ldres, Out, ldo, out_f32)) return sconv3_c64_fwd(g, In, Wk, bias, Res, Out, st);
     if (sconv_in_fwd_ok(g, In, Wk, Res, Out, ldo, out_f32)) return sconv_in_fwd(g, In, Wk, bias, Out, st);
     if (sconv3_g_fwd_ok(g, In, Wk, Res, ldres, Out, ldo, out_f32)) return sconv3_g_fwd(g, In, Wk, bias, Res, Out, st);
+    if (sconv3_s2_fwd_ok(g, In, Wk, Res, Out, ldo, out_f32)) return sconv3_s2_fwd(g, In, Wk, bias, Out, st);
     return g.mode == MODE_F32 ? fwd_t<float>(g, In, Wk, bias, Res, ldres, Out, ldo, out_f32, st)
                               : fwd_t<bf16>(g, In, Wk, bias, Res, ldres, Out, ldo, out_f32, st);
 }
@@ -714,6 +715,7 @@ int sconv_dgrad(const SConv& g, const void* dOut, long lddo, const void* Wt, voi
                  es * ((double)g.n * g.Ho * g.Wo * g.Cout + Mi * g.Cin), st);
     if (sconv3_c64_dgrad_ok(g, dOut, lddo, Wt, dIn, lddi)) return sconv3_c64_dgrad(g, dOut, Wt, dIn, accumulate, st);
     if (sconv3_g_dgrad_ok(g, dOut, lddo, Wt, dIn, lddi)) return sconv3_g_dgrad(g, dOut, Wt, dIn, accumulate, st);
+    if (sconv3_s2_dgrad_ok(g, dOut, lddo, Wt, dIn, lddi)) return sconv3_s2_dgrad(g, dOut, Wt, dIn, accumulate, st);
     return g.mode == MODE_F32 ? dgrad_t<float>(g, dOut, lddo, Wt, dIn, lddi, accumulate, st)
                               : dgrad_t<bf16>(g, dOut, lddo, Wt, dIn, lddi, accumulate, st);
 }
@@ -726,6 +728,7 @@ int sconv_wgrad(const SConv& g, const void* In, const void* dOut, long lddo, flo
     if (sconv3_c64_wgrad_ok(g, In, dOut, lddo)) return sconv3_c64_wgrad(g, In, dOut, dWk, dbias, st);
     if (sconv_in_wgrad_ok(g, dOut, lddo)) return sconv_in_wgrad(g, In, dOut, dWk, dbias, st);
     if (sconv3_g_wgrad_ok(g, In, dOut, lddo)) return sconv3_g_wgrad(g, In, dOut, dWk, dbias, st);
+    if (sconv3_s2_wgrad_ok(g, In, dOut, lddo)) return sconv3_s2_wgrad(g, In, dOut, dWk, dbias, st);
     return g.mode == MODE_F32 ? wgrad_t<float>(g, In, dOut, lddo, dWk, dbias, st) : wgrad_t<bf16>(g, In, dOut, lddo, dWk, dbias, st);
 }
 

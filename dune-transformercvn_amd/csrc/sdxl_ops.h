@@ -39,6 +39,13 @@ bool sconv3_g_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* 
 int sconv3_g_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st);
 bool sconv3_g_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo);
 int sconv3_g_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st);
+// 3x3 / stride 2 / pad 0 down-samplers (zeros beyond the map), channels multiples of 64
+bool sconv3_s2_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, const void* Out, long ldo, int out_f32);
+int sconv3_s2_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, hipStream_t st);
+bool sconv3_s2_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi);
+int sconv3_s2_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st);
+bool sconv3_s2_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo);
+int sconv3_s2_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st);
 // conv_in (3 -> 64, sdxl_stem.hip): gather-MFMA forward, weight gradient from the hit list
 bool sconv_in_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, const void* Out, long ldo, int out_f32);
 int sconv_in_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, hipStream_t st);
