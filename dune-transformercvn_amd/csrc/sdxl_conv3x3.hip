@@ -31,6 +31,26 @@ constexpr int CP = 68;                                // fp32 C tile pitch (floa
 constexpr int CT_BYTES = 128 * CP * 4;                // 34 816
 constexpr int NCHUNK = PH * PW * 8;                   // 16-B chunks of a patch (2 720)
 
+// Tile -> pixel mapping of the 8 x 32 stride-1 tile.  Large maps: tiles_x x tiles_y tiles per image.  Small maps would waste most
+// of a tile (a 7 x 5 map fills 14 % of it) and re-read the weights once per image, so maps of width <= 15 are PACKED side by side
+// (px images per tile row, one zero column between neighbours -- the padding both of them need) and maps of height <= 3 are stacked
+// (py per tile).  A tile then carries px * py images.
+struct TileMap {
+    int n, H, W, tiles_x, tiles_y, px, py;
+    __host__ __device__ int ntiles() const { return ((n + px * py - 1) / (px * py)) * tiles_x * tiles_y; }
+    // pixel of tile t at tile-relative (ry, rx), ry in [-1, 8], rx in [-1, 32]; false = zero padding / outside / no such image
+    __device__ __forceinline__ bool pixel(int t, int ry, int rx, int& img, int& y, int& x) const {
+        const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, grp = r / tiles_y;
+        int sx = 0, sy = 0;
+        if (px > 1) { if (rx < 0) return false; sx = rx / (W + 1); x = rx - sx * (W + 1); if (sx >= px) return false; }
+        else x = tx * TW + rx;
+        if (py > 1) { if (ry < 0) return false; sy = ry / (H + 1); y = ry - sy * (H + 1); if (sy >= py) return false; }
+        else y = ty * TH + ry;
+        img = grp * (px * py) + sy * px + sx;
+        return x >= 0 && x < W && y >= 0 && y < H && img < n;
+    }
+};
+
 // barrier that orders LDS traffic only: __syncthreads() would also wait for every outstanding global store (vmcnt(0))
 __device__ __forceinline__ void lds_barrier_() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -164,6 +184,16 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
     }
 }
 
+TileMap make_map(int n, int H, int W) {
+    TileMap m{};
+    m.n = n; m.H = H; m.W = W;
+    m.px = W <= 15 ? TW / (W + 1) : 1;
+    m.py = (H <= 3 && m.px > 1) ? TH / (H + 1) : 1;                // stacking only together with side-by-side packing
+    m.tiles_x = m.px > 1 ? 1 : (W + TW - 1) / TW;
+    m.tiles_y = m.py > 1 ? 1 : (H + TH - 1) / TH;
+    return m;
+}
+
 constexpr size_t C64_SMEM = 2 * PATCH_BYTES + CT_BYTES;       // 132 736
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -178,7 +208,7 @@ struct CGArgs {
     const bf16* In; const bf16* W; const float* bias; const bf16* Res; bf16* Out;
     int n, H, W_, flip;
     int cin, cout, nc;                                  // channels of this pass' input / output, cin / 64
-    int tiles_x, tiles_y, ntiles;
+    TileMap map; int ntiles;
 };
 
 __global__ __launch_bounds__(512, 1) void k_sconv3_g(const CGArgs g) {
@@ -200,13 +230,11 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_g(const CGArgs g) {
     }
     const int dq = lane / 9, dslot = lane - dq * 9;
     auto issue = [&](int t, int chunk, int buf) {
-        const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
-        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
         for (int j = wave; j * 7 < PH * PW; j += 8) {
             const int pix = j * 7 + dq;
             const int py = pix / PW, px = pix - py * PW;
-            const int y = y0 + py, x = x0 + px;
-            const bool ok = dslot < 8 && pix < PH * PW && y >= 0 && y < g.H && x >= 0 && x < g.W_;
+            int img = 0, y = 0, x = 0;
+            const bool ok = g.map.pixel(t, py - 1, px - 1, img, y, x) && dslot < 8 && pix < PH * PW;
             const bf16* src = ok ? g.In + (((long)img * g.H + y) * g.W_ + x) * g.cin + chunk * 64 + dslot * 8
                                  : reinterpret_cast<const bf16*>(g_zero_line);
             if (lane < 63)
@@ -253,7 +281,6 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_g(const CGArgs g) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // next patch + next fragments; in front of the epilogue's stores
         if (chunk == g.nc - 1) {
-            const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 if ((wp >> 1) == pass) {
@@ -267,8 +294,8 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_g(const CGArgs g) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int idx = tid + i * 512, pos = idx >> 3, ch = idx & 7;
-                    const int y = ty * TH + pass * 4 + (pos >> 5), x = tx * TW + (pos & 31);
-                    if (y < g.H && x < g.W_) {
+                    int img = 0, y = 0, x = 0;
+                    if (g.map.pixel(t, pass * 4 + (pos >> 5), pos & 31, img, y, x)) {
                         const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + pos * CP + ch * 8);
                         const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cs + pos * CP + ch * 8 + 4);
                         float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -521,7 +548,7 @@ int launch_g(const SConv& g, const void* In, int cin, const void* W, int cout, c
     a.In = reinterpret_cast<const bf16*>(In); a.W = reinterpret_cast<const bf16*>(W); a.bias = bias;
     a.Res = reinterpret_cast<const bf16*>(Res); a.Out = reinterpret_cast<bf16*>(Out);
     a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.flip = flip; a.cin = cin; a.cout = cout; a.nc = cin / 64;
-    a.tiles_x = (g.Win + TW - 1) / TW; a.tiles_y = (g.Hin + TH - 1) / TH; a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    a.map = make_map(g.n, g.Hin, g.Win); a.ntiles = a.map.ntiles();
     static bool attr = false;
     if (!attr) {
         TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_SMEM));
@@ -572,7 +599,7 @@ __device__ __forceinline__ int swz(int pix, int chunk, int sub) { return pix * 1
 
 constexpr int WG_PATCH = PH * PW * 128;               // 43 520
 constexpr int WG_DOUT = TH * TW * 128;                // 32 768
-constexpr size_t WG_SMEM = WG_PATCH + WG_DOUT;                      // stride 1; the stride-2 instance needs less
+constexpr size_t WG_SMEM = WG_PATCH + WG_DOUT + PH * PW * 4;        // stride 1 (+ the packed-map table); the stride-2 instance needs less
 
 struct W64Args {
     const bf16* In; const bf16* dOut; float* slab; float* bslab;
@@ -580,11 +607,12 @@ struct W64Args {
     int tiles_x, tiles_y, ntiles;
     int cin, cout;                        // row strides; blockIdx.y selects the (64 c) x (64 n) sub-block: c chunk fastest
     int Hi, Wi;                           // input map
+    TileMap map;                          // stride 1: tile -> pixel mapping (small maps packed)
 };
 
 // S = 1: 3x3 / stride 1 / pad 1 (8 x 32 output tile, 10 x 34 patch); S = 2: 3x3 / stride 2 / pad 0 with zeros beyond the map
 // (diffusers' F.pad(0,1,0,1) down-sampler: 2 x 32 output tile, 5 x 65 patch, input pixel = 2 * output pixel + tap)
-template <int S>
+template <int S, bool PACK>
 __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
     constexpr int OTH = S == 1 ? 8 : 2;                            // output tile rows
     constexpr int PHs = S * OTH + (S == 1 ? 2 : 1), PWs = S * TW + (S == 1 ? 2 : 1), ORG = S == 1 ? 1 : 0;
@@ -593,7 +621,27 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
     constexpr int PATCH_B = PHs * PWs * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;                                            // [PH*PW][128 B] In halo patch
-    char* dout = smem + PATCH_B;                                  // [TH*TW][128 B] output-gradient tile
+    char* dout = smem + PATCH_B;
+    // packed small maps: tile-independent part of the tile -> pixel mapping, one entry per patch pixel:
+    // (image slot within the group) << 24 | pixel offset within the group's images, -1 = padding
+    int* ptab = reinterpret_cast<int*>(smem + PATCH_B + OTH * TW * 128);
+    if (PACK) {
+        for (int p = threadIdx.x; p < PHs * PWs; p += 256) {
+            const int ry = p / PWs - 1, rx = p % PWs - 1;
+            int e = -1;                                            // packing in y implies packing in x (make_map); x-only packing
+            if (rx >= 0 && (g.map.py == 1 || ry >= 0)) {           // keeps y for the use site (rows follow the y tile)
+                const int sx = rx / (g.map.W + 1), x = rx - sx * (g.map.W + 1);
+                int sy = 0, y = 0;
+                if (g.map.py > 1) { sy = ry / (g.map.H + 1); y = ry - sy * (g.map.H + 1); }
+                if (sx < g.map.px && x < g.map.W && (g.map.py == 1 || (sy < g.map.py && y < g.map.H))) {
+                    const int slot = sy * g.map.px + sx;
+                    e = (slot << 24) | (slot * g.map.H * g.map.W + y * g.map.W + x);
+                }
+            }
+            ptab[p] = e;
+        }
+        __syncthreads();
+    }                                  // [TH*TW][128 B] output-gradient tile
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 1, wn = wave & 1;                       // input-channel half, output-channel half
     const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
@@ -615,22 +663,41 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
     for (int t = lb; t < g.ntiles; t += nb) {
         const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
         const int y0 = ty * OTH, x0 = tx * TW;
+        const int gbase = img * (g.map.px * g.map.py);             // first image of this tile's group (packed maps)
         __syncthreads();                                           // previous tile's readers are done
         {
-            u16x8 v[NPL];
+            // two batches: the tile mapping of the packed small maps needs registers too, and this kernel sits at the 256-register
+            // limit of two workgroups per CU
+            constexpr int NBAT = PACK ? 2 : 1, NPH = (NPL + NBAT - 1) / NBAT;
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) {
-                const int idx = tid + i * 256, pix = idx >> 3, ch = idx & 7;
-                const int py = pix / PWs, px = pix - py * PWs;
-                const int y = S * y0 - ORG + py, x = S * x0 - ORG + px;
-                v[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (idx < NPC && y >= 0 && y < g.Hi && x >= 0 && x < g.Wi)
-                    v[i] = *reinterpret_cast<const u16x8*>(g.In + (((long)img * g.Hi + y) * g.Wi + x) * g.cin + c0 + ch * 8);
-            }
+            for (int hb = 0; hb < NBAT; ++hb) {
+                u16x8 v[NPH];
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) {
-                const int idx = tid + i * 256, pix = idx >> 3, ch = idx & 7;
-                if (idx < NPC) *reinterpret_cast<u16x8*>(patch + swz(pix, ch, 0)) = v[i];
+                for (int i = 0; i < NPH; ++i) {
+                    const int idx = tid + (hb * NPH + i) * 256, pix = idx >> 3, ch = idx & 7;
+                    const int py = pix / PWs, px = pix - py * PWs;
+                    int im = img, y = S * y0 - ORG + py, x = S * x0 - ORG + px;
+                    bool ok = idx < NPC;
+                    v[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (PACK) {                                    // tiles of packed maps: t = image group (unless the map is tiled in y)
+                        const int e = ok ? ptab[pix] : -1;
+                        if (e >= 0 && gbase + (e >> 24) < g.n && g.map.py > 1)
+                            v[i] = *reinterpret_cast<const u16x8*>(g.In + ((long)gbase * g.Hi * g.Wi + (e & 0xffffff)) * g.cin + c0 + ch * 8);
+                        else if (e >= 0 && gbase + (e >> 24) < g.n) {           // packed in x only: rows follow the y tile
+                            const int yy = ty * OTH + py - 1, slot = e >> 24, xx = (e & 0xffffff) - slot * g.Hi * g.Wi;      // y == ry here
+                            if (yy >= 0 && yy < g.Hi)
+                                v[i] = *reinterpret_cast<const u16x8*>(g.In + (((long)(gbase + slot) * g.Hi + yy) * g.Wi + xx) * g.cin + c0 + ch * 8);
+                        }
+                    } else {
+                        ok = ok && y >= 0 && y < g.Hi && x >= 0 && x < g.Wi;
+                        if (ok) v[i] = *reinterpret_cast<const u16x8*>(g.In + (((long)im * g.Hi + y) * g.Wi + x) * g.cin + c0 + ch * 8);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NPH; ++i) {
+                    const int idx = tid + (hb * NPH + i) * 256, pix = idx >> 3, ch = idx & 7;
+                    if (idx < NPC) *reinterpret_cast<u16x8*>(patch + swz(pix, ch, 0)) = v[i];
+                }
             }
         }
         {
@@ -638,9 +705,21 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
 #pragma unroll
             for (int i = 0; i < NDL; ++i) {
                 const int idx = tid + i * 256, pos = idx >> 3, ch = idx & 7;
-                const int y = y0 + (pos >> 5), x = x0 + (pos & 31);
+                int im = img, y = y0 + (pos >> 5), x = x0 + (pos & 31);
+                bool ok = true;
                 d[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (y < g.H && x < g.W_) d[i] = *reinterpret_cast<const u16x8*>(g.dOut + (((long)img * g.H + y) * g.W_ + x) * g.cout + n0 + ch * 8);
+                if (PACK) {
+                    const int e = ptab[((pos >> 5) + 1) * PWs + (pos & 31) + 1];
+                    if (e >= 0 && gbase + (e >> 24) < g.n && g.map.py > 1)
+                        d[i] = *reinterpret_cast<const u16x8*>(g.dOut + ((long)gbase * g.H * g.W_ + (e & 0xffffff)) * g.cout + n0 + ch * 8);
+                    else if (e >= 0 && gbase + (e >> 24) < g.n) {
+                        const int yy = ty * OTH + (pos >> 5), slot = e >> 24, xx = (e & 0xffffff) - slot * g.H * g.W_;
+                        if (yy < g.H) d[i] = *reinterpret_cast<const u16x8*>(g.dOut + (((long)(gbase + slot) * g.H + yy) * g.W_ + xx) * g.cout + n0 + ch * 8);
+                    }
+                } else {
+                    ok = y < g.H && x < g.W_;
+                    if (ok) d[i] = *reinterpret_cast<const u16x8*>(g.dOut + (((long)im * g.H + y) * g.W_ + x) * g.cout + n0 + ch * 8);
+                }
             }
 #pragma unroll
             for (int i = 0; i < NDL; ++i) {
@@ -775,7 +854,7 @@ int sconv3_g_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk,
     W64Args a{};
     a.In = reinterpret_cast<const bf16*>(In); a.dOut = reinterpret_cast<const bf16*>(dOut);
     a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.cin = g.Cin; a.cout = g.Cout; a.Hi = g.Hin; a.Wi = g.Win;
-    a.tiles_x = (g.Win + TW - 1) / TW; a.tiles_y = (g.Hin + TH - 1) / TH; a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    a.map = make_map(g.n, g.Hin, g.Win); a.tiles_x = a.map.tiles_x; a.tiles_y = a.map.tiles_y; a.ntiles = a.map.ntiles();
     const int ncc = g.Cin / 64, nsub = ncc * (g.Cout / 64);
     int gx = 512 / nsub;                                           // slab holds 512 sub-block partials; two workgroups per CU
     if (gx > a.ntiles) gx = a.ntiles;
@@ -783,10 +862,19 @@ int sconv3_g_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk,
     a.slab = g.slab; a.bslab = nullptr;
     static bool attr = false;
     if (!attr) {
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
         attr = true;
     }
-    hipLaunchKernelGGL(k_sconv3_c64_wgrad<1>, dim3(gx, nsub), dim3(256), WG_SMEM, st, a);
+    if (a.map.px > 1 || a.map.py > 1) {
+        static bool attr2 = false;
+        if (!attr2) {
+            TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL((k_sconv3_c64_wgrad<1, true>), dim3(gx, nsub), dim3(256), WG_SMEM, st, a);
+    } else {
+        hipLaunchKernelGGL((k_sconv3_c64_wgrad<1, false>), dim3(gx, nsub), dim3(256), WG_SMEM, st, a);
+    }
     TCVN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sub_reduce, dim3((64 * 576 + 255) / 256, nsub), dim3(256), 0, st, a.slab, gx, nsub, ncc, g.Cin, dWk);
     TCVN_LAUNCH_CHECK();
@@ -859,7 +947,7 @@ int sconv3_s2_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk
     if (gx > a.ntiles) gx = a.ntiles;
     if (gx < 1) gx = 1;
     a.slab = g.slab; a.bslab = nullptr;
-    hipLaunchKernelGGL(k_sconv3_c64_wgrad<2>, dim3(gx, nsub), dim3(256), (size_t)(5 * 65 * 128 + 2 * TW * 128), st, a);
+    hipLaunchKernelGGL((k_sconv3_c64_wgrad<2, false>), dim3(gx, nsub), dim3(256), (size_t)(5 * 65 * 128 + 2 * TW * 128), st, a);
     TCVN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sub_reduce, dim3((64 * 576 + 255) / 256, nsub), dim3(256), 0, st, a.slab, gx, nsub, ncc, g.Cin, dWk);
     TCVN_LAUNCH_CHECK();
@@ -887,10 +975,10 @@ int sconv3_c64_wgrad(const SConv& g, const void* In, const void* dOut, float* dW
     a.slab = g.slab; a.bslab = g.slab + (long)grid * 64 * 576;
     static bool attr = false;
     if (!attr) {
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
         attr = true;
     }
-    hipLaunchKernelGGL(k_sconv3_c64_wgrad<1>, dim3(grid), dim3(256), WG_SMEM, st, a);
+    hipLaunchKernelGGL((k_sconv3_c64_wgrad<1, false>), dim3(grid), dim3(256), WG_SMEM, st, a);
     TCVN_LAUNCH_CHECK();
     SlabJob none{};
     SlabJob jw = slab_job(a.slab, grid, 64L * 576, dWk, 0);
