@@ -220,14 +220,21 @@ int tcvn_sdxl::forward(int n, const int32_t* coords, const float* values, long n
         ScatterArgs a{cfg.mode, coords, values, nnz, n, ws + L.act[0], cfg.H, cfg.W, cfg.in_ch, log_pixels, train ? noise_std : 0.f, seed};
         if ((rc = scatter_pixels(a, st))) return rc;
     }
+    // a buffer consumed by exactly one GroupNorm and produced by a convolution gets its statistics from that convolution's epilogue
+    std::vector<int> gn_of(bufs.size(), -1), conv_made(bufs.size(), 0);
+    for (const auto& o : ops) {
+        if (o.kind == OP_GN) gn_of[o.in] = gn_of[o.in] == -1 ? o.gn_id : -2;
+        else if (!o.final_f32) conv_made[o.out] = 1;
+    }
     for (const auto& o : ops) {
         if (o.kind == OP_GN) {
             GnArgs a{cfg.mode, ws + L.act[o.in], bufs[o.in].C, n, bufs[o.in].H * bufs[o.in].W, bufs[o.in].C, data[o.w], data[o.b], kGnEps, o.act,
                      reinterpret_cast<double*>(ws + L.stats) + (long)o.gn_id * n * 2};
-            if ((rc = gn_stats(a, st))) return rc;
+            if (!(gn_of[o.in] >= 0 && conv_made[o.in]) && (rc = gn_stats(a, st))) return rc;
             if ((rc = gn_act(a, ws + L.act[o.out], bufs[o.out].C, st))) return rc;
         } else {
-            const SConv g = geom(o, n);
+            SConv g = geom(o, n);
+            if (!o.final_f32 && gn_of[o.out] >= 0) g.stats = reinterpret_cast<double*>(ws + L.stats) + (long)gn_of[o.out] * n * 2;
             void* dst = o.final_f32 ? reinterpret_cast<void*>(out) : reinterpret_cast<void*>(ws + L.act[o.out]);
             const long ldo = o.final_f32 ? out_ld : g.Cout;
             if ((rc = sconv_fwd(g, ws + L.act[o.in], ws + L.wk[o.conv_id], data[o.b], o.res >= 0 ? ws + L.act[o.res] : nullptr,

@@ -54,6 +54,17 @@ struct TileMap {
 // barrier that orders LDS traffic only: __syncthreads() would also wait for every outstanding global store (vmcnt(0))
 __device__ __forceinline__ void lds_barrier_() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// GroupNorm statistics of a tile's STORED values (sum, sum of squares over pixels x channels of one image), fused into the producing
+// convolution's epilogue: wave partials through two LDS float atomics, one pair of fp64 atomics per tile by thread 0 afterwards.
+__device__ __forceinline__ void stats_wave_add(float s, float ss, float* lacc) {
+    s = wave_sum(s); ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&lacc[0], s); atomicAdd(&lacc[1], ss); }
+}
+__device__ __forceinline__ void stats_flush(float* lacc, double* stats, int img) {      // thread 0, after a barrier behind the adds
+    atomicAdd(stats + 2 * img, (double)lacc[0]); atomicAdd(stats + 2 * img + 1, (double)lacc[1]);
+    lacc[0] = 0.f; lacc[1] = 0.f;
+}
+
 __device__ __attribute__((aligned(16))) unsigned int g_zero_line[4];       // 16 B of zeros: LDS-DMA source of padding
 
 #ifdef TCVN_PHASE_PROF
@@ -66,7 +77,7 @@ __device__ unsigned long long g_ph2[16];
 #endif
 
 struct C64Args {
-    const bf16* In; const bf16* W; const float* bias; const bf16* Res; bf16* Out;
+    const bf16* In; const bf16* W; const float* bias; const bf16* Res; bf16* Out; double* stats;
     int n, H, W_, flip;
     int tiles_x, tiles_y, ntiles;
 };
@@ -75,6 +86,8 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;                                            // [2][PATCH_BYTES]
     float* Cs = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES);  // [128][CP]
+    float* lacc = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES + CT_BYTES);     // [2] statistics of the tile
+    if (threadIdx.x == 0) { lacc[0] = 0.f; lacc[1] = 0.f; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wp = wave >> 1, wn = wave & 1;                       // tile rows 2wp, 2wp+1; output channels [32wn, +32)
@@ -147,6 +160,7 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
         PH2(2)
         // epilogue: two passes of 128 positions (tile rows 0-3, 4-7) through the fp32 C tile
         const int tx = t % g.tiles_x, r = t / g.tiles_x, ty = r % g.tiles_y, img = r / g.tiles_y;
+        float ts = 0.f, tss = 0.f;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             if ((wp >> 1) == pass) {
@@ -174,13 +188,19 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_c64(const C64Args g) {
                     u16x8 ov;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) ov[j] = f2bf(v[j]);
+                    if (g.stats) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { const float f = bf2f(ov[j]); ts += f; tss += f * f; }
+                    }
                     *reinterpret_cast<u16x8*>(g.Out + o) = ov;
                 }
             }
             if (pass == 0) lds_barrier_();
         }
+        if (g.stats) stats_wave_add(ts, tss, lacc);
         PH2(3)
         lds_barrier_();                                          // C tile free again, next patch complete
+        if (g.stats && threadIdx.x == 0) stats_flush(lacc, g.stats, img);
     }
 }
 
@@ -194,7 +214,7 @@ TileMap make_map(int n, int H, int W) {
     return m;
 }
 
-constexpr size_t C64_SMEM = 2 * PATCH_BYTES + CT_BYTES;       // 132 736
+constexpr size_t C64_SMEM = 2 * PATCH_BYTES + CT_BYTES + 16;       // 132 736
 
 // ---------------------------------------------------------------------------------------------------------------------
 // General width (input and output channels multiples of 64; the 128 / 256 / 512-channel stages): same tile, same patch, but the
@@ -205,7 +225,7 @@ constexpr size_t C64_SMEM = 2 * PATCH_BYTES + CT_BYTES;       // 132 736
 // nothing the MFMAs wait for is queued behind an HBM access.
 // ---------------------------------------------------------------------------------------------------------------------
 struct CGArgs {
-    const bf16* In; const bf16* W; const float* bias; const bf16* Res; bf16* Out;
+    const bf16* In; const bf16* W; const float* bias; const bf16* Res; bf16* Out; double* stats;   // stats: unpacked maps only
     int n, H, W_, flip;
     int cin, cout, nc;                                  // channels of this pass' input / output, cin / 64
     TileMap map; int ntiles;
@@ -215,6 +235,8 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_g(const CGArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
     float* Cs = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES);
+    float* lacc = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES + CT_BYTES);
+    if (threadIdx.x == 0) { lacc[0] = 0.f; lacc[1] = 0.f; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wp = wave >> 1, wn = wave & 1;
@@ -281,6 +303,7 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_g(const CGArgs g) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // next patch + next fragments; in front of the epilogue's stores
         if (chunk == g.nc - 1) {
+            float ts = 0.f, tss = 0.f;
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 if ((wp >> 1) == pass) {
@@ -308,17 +331,23 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_g(const CGArgs g) {
                         u16x8 ov;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) ov[j] = f2bf(v[j]);
+                    if (g.stats) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { const float f = bf2f(ov[j]); ts += f; tss += f * f; }
+                    }
                         *reinterpret_cast<u16x8*>(g.Out + o) = ov;
                     }
                 }
                 if (pass == 0) lds_barrier_();
             }
+            if (g.stats) stats_wave_add(ts, tss, lacc);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
         }
         lds_barrier_();
+        if (g.stats && chunk == g.nc - 1 && threadIdx.x == 0) stats_flush(lacc, g.stats, t / (g.map.tiles_x * g.map.tiles_y));
         if (!more) break;
         t = nt; chunk = nchunk; buf ^= 1;
     }
@@ -331,10 +360,10 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_g(const CGArgs g) {
 // input pixel = 2 * output pixel + tap.  Input-bound: four input pixels are read per output pixel.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int S2_PH = 5, S2_PW = 65;                  // patch of a 2 x 32 output tile
-constexpr size_t S2_SMEM = 2 * PATCH_BYTES + 64 * CP * 4;
+constexpr size_t S2_SMEM = 2 * PATCH_BYTES + 64 * CP * 4 + 16;
 
 struct S2Args {
-    const bf16* In; const bf16* W; const float* bias; bf16* Out;
+    const bf16* In; const bf16* W; const float* bias; bf16* Out; double* stats;
     int n, Hi, Wi, Ho, Wo, cin, cout, nc;
     int tiles_x, tiles_y, ntiles;
 };
@@ -343,6 +372,8 @@ __global__ __launch_bounds__(256, 1) void k_sconv3_s2_fwd(const S2Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
     float* Cs = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES);
+    float* lacc = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES + 64 * CP * 4);
+    if (threadIdx.x == 0) { lacc[0] = 0.f; lacc[1] = 0.f; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wr = wave >> 1, wn = wave & 1;                       // output tile row, channel half
@@ -409,6 +440,7 @@ __global__ __launch_bounds__(256, 1) void k_sconv3_s2_fwd(const S2Args g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) Cs[(wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + 32 * wn + l31] = acc[e] + bias;
             lds_barrier_();
+            float ts = 0.f, tss = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int idx = tid + i * 256, pos = idx >> 3, ch = idx & 7;     // 64 positions x 8 chunks
@@ -419,13 +451,17 @@ __global__ __launch_bounds__(256, 1) void k_sconv3_s2_fwd(const S2Args g) {
                     u16x8 ov;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { ov[j] = f2bf(c0[j]); ov[4 + j] = f2bf(c1[j]); }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float f = bf2f(ov[j]); ts += f; tss += f * f; }
                     *reinterpret_cast<u16x8*>(g.Out + (((long)img * g.Ho + y) * g.Wo + x) * g.cout + n0 + ch * 8) = ov;
                 }
             }
+            if (g.stats) stats_wave_add(ts, tss, lacc);
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         }
         lds_barrier_();
+        if (g.stats && chunk == g.nc - 1 && threadIdx.x == 0) stats_flush(lacc, g.stats, t / (g.tiles_x * g.tiles_y));
         if (!more) break;
         t = nt; chunk = nchunk; buf ^= 1;
     }
@@ -543,12 +579,13 @@ __global__ __launch_bounds__(512, 1) void k_sconv3_s2_dgrad(const D2Args g) {
 }
 
 int launch_g(const SConv& g, const void* In, int cin, const void* W, int cout, const float* bias, const void* Res, void* Out, int flip,
-             hipStream_t st) {
+             double* stats, hipStream_t st) {
     CGArgs a{};
     a.In = reinterpret_cast<const bf16*>(In); a.W = reinterpret_cast<const bf16*>(W); a.bias = bias;
     a.Res = reinterpret_cast<const bf16*>(Res); a.Out = reinterpret_cast<bf16*>(Out);
     a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.flip = flip; a.cin = cin; a.cout = cout; a.nc = cin / 64;
     a.map = make_map(g.n, g.Hin, g.Win); a.ntiles = a.map.ntiles();
+    a.stats = (a.map.px == 1 && a.map.py == 1) ? stats : nullptr;
     static bool attr = false;
     if (!attr) {
         TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64_SMEM));
@@ -560,8 +597,10 @@ int launch_g(const SConv& g, const void* In, int cin, const void* W, int cout, c
     return 0;
 }
 
-int launch_c64(const SConv& g, const void* In, const void* W, const float* bias, const void* Res, void* Out, int flip, hipStream_t st) {
+int launch_c64(const SConv& g, const void* In, const void* W, const float* bias, const void* Res, void* Out, int flip, double* stats,
+               hipStream_t st) {
     C64Args a{};
+    a.stats = stats;
     a.In = reinterpret_cast<const bf16*>(In); a.W = reinterpret_cast<const bf16*>(W); a.bias = bias;
     a.Res = reinterpret_cast<const bf16*>(Res); a.Out = reinterpret_cast<bf16*>(Out);
     a.n = g.n; a.H = g.Hin; a.W_ = g.Win; a.flip = flip;
@@ -785,27 +824,28 @@ bool geom_g_ok(const SConv& g) {
 bool sconv3_g_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, long ldres, const void* Out, long ldo, int out_f32) {
     return geom_g_ok(g) && !out_f32 && ldo == g.Cout && (Res == nullptr || ldres == g.Cout) && al16(In) && al16(Wk) && al16(Res) && al16(Out);
 }
-int sconv3_g_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, hipStream_t st) {
-    return launch_g(g, In, g.Cin, Wk, g.Cout, bias, Res, Out, 0, st);
+bool sconv3_g_fuses_stats(const SConv& g) { const TileMap m = make_map(g.n, g.Hin, g.Win); return m.px == 1 && m.py == 1; }
+int sconv3_g_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, double* stats, hipStream_t st) {
+    return launch_g(g, In, g.Cin, Wk, g.Cout, bias, Res, Out, 0, stats, st);
 }
 bool sconv3_g_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi) {
     return geom_g_ok(g) && lddo == g.Cout && lddi == g.Cin && al16(dOut) && al16(Wt) && al16(dIn);
 }
 int sconv3_g_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st) {
-    return launch_g(g, dOut, g.Cout, Wt, g.Cin, nullptr, accumulate ? dIn : nullptr, dIn, 1, st);
+    return launch_g(g, dOut, g.Cout, Wt, g.Cin, nullptr, accumulate ? dIn : nullptr, dIn, 1, nullptr, st);
 }
 
 bool sconv3_c64_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, long ldres, const void* Out, long ldo, int out_f32) {
     return geom_ok(g) && !out_f32 && ldo == 64 && (Res == nullptr || ldres == 64) && al16(In) && al16(Wk) && al16(Res) && al16(Out);
 }
-int sconv3_c64_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, hipStream_t st) {
-    return launch_c64(g, In, Wk, bias, Res, Out, 0, st);
+int sconv3_c64_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, double* stats, hipStream_t st) {
+    return launch_c64(g, In, Wk, bias, Res, Out, 0, stats, st);
 }
 bool sconv3_c64_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi) {
     return geom_ok(g) && lddo == 64 && lddi == 64 && al16(dOut) && al16(Wt) && al16(dIn);
 }
 int sconv3_c64_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st) {
-    return launch_c64(g, dOut, Wt, nullptr, accumulate ? dIn : nullptr, dIn, 1, st);
+    return launch_c64(g, dOut, Wt, nullptr, accumulate ? dIn : nullptr, dIn, 1, nullptr, st);
 }
 
 namespace {
@@ -899,8 +939,9 @@ bool geom_s2_ok(const SConv& g) {
 bool sconv3_s2_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, const void* Out, long ldo, int out_f32) {
     return geom_s2_ok(g) && Res == nullptr && !out_f32 && ldo == g.Cout && al16(In) && al16(Wk) && al16(Out);
 }
-int sconv3_s2_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, hipStream_t st) {
+int sconv3_s2_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, double* stats, hipStream_t st) {
     S2Args a{};
+    a.stats = stats;
     a.In = reinterpret_cast<const bf16*>(In); a.W = reinterpret_cast<const bf16*>(Wk); a.bias = bias; a.Out = reinterpret_cast<bf16*>(Out);
     a.n = g.n; a.Hi = g.Hin; a.Wi = g.Win; a.Ho = g.Ho; a.Wo = g.Wo; a.cin = g.Cin; a.cout = g.Cout; a.nc = g.Cin / 64;
     a.tiles_x = (g.Wo + TW - 1) / TW; a.tiles_y = (g.Ho + 1) / 2; a.ntiles = g.n * a.tiles_x * a.tiles_y;

@@ -699,12 +699,26 @@ int sconv_fwd(const SConv& g, const void* In, const void* Wk, const float* bias,
     char nm[96];
     ProfScope ps(label(nm, sizeof(nm), "fwd", g), 2.0 * M * g.Cout * g.ks * g.ks * g.Cin,
                  es * ((double)g.n * g.Hin * g.Win * g.Cin + M * g.Cout * (Res ? 2.0 : 1.0)), st);
-    if (sconv3_c64_fwd_ok(g, In, Wk, Res, ldres, Out, ldo, out_f32)) return sconv3_c64_fwd(g, In, Wk, bias, Res, Out, st);
-    if (sconv_in_fwd_ok(g, In, Wk, Res, Out, ldo, out_f32)) return sconv_in_fwd(g, In, Wk, bias, Out, st);
-    if (sconv3_g_fwd_ok(g, In, Wk, Res, ldres, Out, ldo, out_f32)) return sconv3_g_fwd(g, In, Wk, bias, Res, Out, st);
-    if (sconv3_s2_fwd_ok(g, In, Wk, Res, Out, ldo, out_f32)) return sconv3_s2_fwd(g, In, Wk, bias, Out, st);
-    return g.mode == MODE_F32 ? fwd_t<float>(g, In, Wk, bias, Res, ldres, Out, ldo, out_f32, st)
-                              : fwd_t<bf16>(g, In, Wk, bias, Res, ldres, Out, ldo, out_f32, st);
+    // g.stats: the consumer GroupNorm's statistics.  The tile kernels accumulate them in their epilogue; any other path is followed by
+    // the stand-alone statistics pass, so the caller never runs one for a convolution it handed `stats` to.
+    int rc;
+    bool fused = true;
+    if (sconv3_c64_fwd_ok(g, In, Wk, Res, ldres, Out, ldo, out_f32)) rc = sconv3_c64_fwd(g, In, Wk, bias, Res, Out, g.stats, st);
+    else if (sconv_in_fwd_ok(g, In, Wk, Res, Out, ldo, out_f32)) rc = sconv_in_fwd(g, In, Wk, bias, Out, g.stats, st);
+    else if (sconv3_g_fwd_ok(g, In, Wk, Res, ldres, Out, ldo, out_f32)) {
+        fused = sconv3_g_fuses_stats(g);
+        rc = sconv3_g_fwd(g, In, Wk, bias, Res, Out, g.stats, st);
+    } else if (sconv3_s2_fwd_ok(g, In, Wk, Res, Out, ldo, out_f32)) rc = sconv3_s2_fwd(g, In, Wk, bias, Out, g.stats, st);
+    else {
+        fused = false;
+        rc = g.mode == MODE_F32 ? fwd_t<float>(g, In, Wk, bias, Res, ldres, Out, ldo, out_f32, st)
+                                : fwd_t<bf16>(g, In, Wk, bias, Res, ldres, Out, ldo, out_f32, st);
+    }
+    if (rc == 0 && g.stats != nullptr && !fused) {
+        GnArgs ga{g.mode, Out, ldo, g.n, g.Ho * g.Wo, g.Cout, nullptr, nullptr, 0.f, 0, g.stats};
+        rc = gn_stats(ga, st);
+    }
+    return rc;
 }
 int sconv_dgrad(const SConv& g, const void* dOut, long lddo, const void* Wt, void* dIn, long lddi, int accumulate, hipStream_t st) {
     if (g.n <= 0) return 0;

@@ -17,6 +17,8 @@ struct SConv {
     int Kp, Kpt;                            // padded K of the forward ([Cout][Kp], k = tap*Cin + c) and transposed ([Cin][Kpt], k = tap*Cout + n) packs
     float* slab; long slab_bytes;           // optional scratch for per-workgroup partial weight gradients (sconv_wgrad fast path)
     const int* hits; long nnz;              // optional: COO list (image, y, x) of the non-zero input pixels (conv_in weight gradient)
+    double* stats;                          // optional (forward): [n][2] per-image (sum, sum of squares) of the stored output, pre-zeroed --
+                                            // the GroupNorm statistics of the consumer, accumulated by the convolution's epilogue
 };
 constexpr long kSconvSlabBytes = 512L * (64 * 576 + 64) * 4;     // what the 64 -> 64 weight-gradient kernel asks for
 
@@ -29,26 +31,27 @@ int sconv_wgrad(const SConv& g, const void* In, const void* dOut, long lddo, flo
 
 // bf16 fast paths for 3x3 / stride 1 / pad 1, 64 -> 64 channels (sdxl_conv3x3.hip): halo patch in LDS, weights in registers
 bool sconv3_c64_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, long ldres, const void* Out, long ldo, int out_f32);
-int sconv3_c64_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, hipStream_t st);
+int sconv3_c64_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, double* stats, hipStream_t st);
 bool sconv3_c64_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi);
 int sconv3_c64_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st);
 // general width (channels multiples of 64, <= 512): chunked patch, weight fragments streamed from L2
 bool sconv3_g_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, long ldres, const void* Out, long ldo, int out_f32);
-int sconv3_g_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, hipStream_t st);
+bool sconv3_g_fuses_stats(const SConv& g);
+int sconv3_g_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, const void* Res, void* Out, double* stats, hipStream_t st);
 bool sconv3_g_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi);
 int sconv3_g_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st);
 bool sconv3_g_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo);
 int sconv3_g_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st);
 // 3x3 / stride 2 / pad 0 down-samplers (zeros beyond the map), channels multiples of 64
 bool sconv3_s2_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, const void* Out, long ldo, int out_f32);
-int sconv3_s2_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, hipStream_t st);
+int sconv3_s2_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, double* stats, hipStream_t st);
 bool sconv3_s2_dgrad_ok(const SConv& g, const void* dOut, long lddo, const void* Wt, const void* dIn, long lddi);
 int sconv3_s2_dgrad(const SConv& g, const void* dOut, const void* Wt, void* dIn, int accumulate, hipStream_t st);
 bool sconv3_s2_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo);
 int sconv3_s2_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st);
 // conv_in (3 -> 64, sdxl_stem.hip): gather-MFMA forward, weight gradient from the hit list
 bool sconv_in_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, const void* Out, long ldo, int out_f32);
-int sconv_in_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, hipStream_t st);
+int sconv_in_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, double* stats, hipStream_t st);
 bool sconv_in_wgrad_ok(const SConv& g, const void* dOut, long lddo);
 int sconv_in_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk, float* dbias, hipStream_t st);
 bool sconv3_c64_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo);

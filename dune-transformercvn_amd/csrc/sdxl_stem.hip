@@ -21,7 +21,7 @@ constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2;
 constexpr int CP = 68;
 
 struct InFwdArgs {
-    const bf16* img; const bf16* W; const float* bias; bf16* Out;
+    const bf16* img; const bf16* W; const float* bias; bf16* Out; double* stats;
     int n, H, W_, tiles_x, tiles_y, ntiles;
 };
 
@@ -29,6 +29,8 @@ __global__ __launch_bounds__(256, 2) void k_sconv_in_fwd(const InFwdArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem_in[];
     float* Cs = reinterpret_cast<float*>(smem_in);                             // [256][CP] fp32, 69 632 B
     bf16* patch = reinterpret_cast<bf16*>(smem_in + TH * TW * CP * 4);         // [PH*PW][3]
+    float* lacc = reinterpret_cast<float*>(smem_in + TH * TW * CP * 4 + (PH * PW * 3 + 8) * 2);   // [2] tile statistics (GroupNorm of the consumer)
+    if (threadIdx.x == 0) { lacc[0] = 0.f; lacc[1] = 0.f; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     // B fragments: W[n][k], k = tap*3 + c (Kp = 32, zero padded): lane (n = l31 of n tile, lh) holds k = ks*16 + lh*8 .. +8
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void k_sconv_in_fwd(const InFwdArgs g) {
             }
         }
         __syncthreads();
+        float ts = 0.f, tss = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * 256, pos = idx >> 3, ch = idx & 7;
@@ -96,7 +99,18 @@ __global__ __launch_bounds__(256, 2) void k_sconv_in_fwd(const InFwdArgs g) {
                 u16x8 ov;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { ov[j] = f2bf(c0[j]); ov[4 + j] = f2bf(c1[j]); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = bf2f(ov[j]); ts += f; tss += f * f; }
                 *reinterpret_cast<u16x8*>(g.Out + (((long)img * g.H + y) * g.W_ + x) * 64 + ch * 8) = ov;
+            }
+        }
+        if (g.stats) {                                             // uniform
+            ts = wave_sum(ts); tss = wave_sum(tss);
+            if (lane == 0) { atomicAdd(&lacc[0], ts); atomicAdd(&lacc[1], tss); }
+            __syncthreads();
+            if (tid == 0) {
+                atomicAdd(g.stats + 2 * img, (double)lacc[0]); atomicAdd(g.stats + 2 * img + 1, (double)lacc[1]);
+                lacc[0] = 0.f; lacc[1] = 0.f;
             }
         }
     }
@@ -180,12 +194,13 @@ bool in_geom_ok(const SConv& g) {
 bool sconv_in_fwd_ok(const SConv& g, const void* In, const void* Wk, const void* Res, const void* Out, long ldo, int out_f32) {
     return in_geom_ok(g) && Res == nullptr && !out_f32 && ldo == 64 && al16(Wk) && al16(Out) && In != nullptr;
 }
-int sconv_in_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, hipStream_t st) {
+int sconv_in_fwd(const SConv& g, const void* In, const void* Wk, const float* bias, void* Out, double* stats, hipStream_t st) {
     InFwdArgs a{};
+    a.stats = stats;
     a.img = reinterpret_cast<const bf16*>(In); a.W = reinterpret_cast<const bf16*>(Wk); a.bias = bias; a.Out = reinterpret_cast<bf16*>(Out);
     a.n = g.n; a.H = g.Hin; a.W_ = g.Win;
     a.tiles_x = (g.Win + TW - 1) / TW; a.tiles_y = (g.Hin + TH - 1) / TH; a.ntiles = g.n * a.tiles_x * a.tiles_y;
-    constexpr size_t smem = TH * TW * CP * 4 + (PH * PW * 3 + 8) * 2;
+    constexpr size_t smem = TH * TW * CP * 4 + (PH * PW * 3 + 8) * 2 + 16;
     static bool attr = false;
     if (!attr) {
         TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv_in_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
