@@ -294,9 +294,155 @@ int launch_wgrad1(const ConvWgradArgs& a, int ntiles, int nchunk, hipStream_t st
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: Out[pos][n_off + n] = bias[n] + sum_c prelu(sc[c]*X[pos][c] + sh[c], sl[c]) * Wk[n][c],  n < 128, + BN statistics of Out
+// A wave owns 32 positions: the activated input of one 64-channel chunk is 32 registers per lane (lane = position, read along the
+// row it sits in, transformed in registers); the 128 x 64 weight chunk goes through LDS, double buffered, 68-float pitch (the b128
+// fragment reads of 16 lanes cover all 64 banks once); chunk k+1's weights and input are in flight under chunk k's 128 MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int WSF = 68;
+
+__global__ __launch_bounds__(256, 2) void k_conv1x1_fwd_f32(const ConvFwdArgs g, int ntiles, int nch) {
+    extern __shared__ __attribute__((aligned(16))) float ws_dyn[];             // [2][128 * WSF]
+    float (*ws)[128 * WSF] = reinterpret_cast<float (*)[128 * WSF]>(ws_dyn);
+    __shared__ __attribute__((aligned(16))) float tab[3 * MAXC];
+    __shared__ double stat[128 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float* __restrict__ X = reinterpret_cast<const float*>(g.A);
+    const float* __restrict__ Wk = reinterpret_cast<const float*>(g.Wk);
+    float* __restrict__ Out = reinterpret_cast<float*>(g.Out);
+    for (int c = tid; c < MAXC; c += 256) {
+        const bool ok = c < g.K;
+        tab[c] = ok ? g.sc[c] : 0.f; tab[MAXC + c] = ok ? g.sh[c] : 0.f; tab[2 * MAXC + c] = ok ? g.sl[c] : 0.f;
+    }
+    stat[tid] = 0.0;
+    // weight chunk loader: 128 rows x 64 floats = 2048 float4, eight per thread
+    const int wr = tid >> 4, wc = (tid & 15) * 4;
+    f32x4 wreg[8], xreg[8];
+    auto issue = [&](int t, int kc) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = wr + 16 * i, k = kc * 64 + wc;
+            wreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k < g.K) wreg[i] = *reinterpret_cast<const f32x4*>(Wk + (long)n * g.Kp + k);
+        }
+        const long pos = (long)t * 128 + wave * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = kc * 64 + lh * 32 + 4 * i;
+            xreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (pos < g.M && k < g.K) xreg[i] = *reinterpret_cast<const f32x4*>(X + pos * g.lda + k);
+        }
+    };
+    float a[32];
+    auto commit = [&](int t, int kc, int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&ws[buf][(wr + 16 * i) * WSF + wc]) = wreg[i];
+        const bool valid = (long)t * 128 + wave * 32 + l31 < g.M;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = kc * 64 + lh * 32 + 4 * i;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(tab + k), sh = *reinterpret_cast<const f32x4*>(tab + MAXC + k),
+                        sl = *reinterpret_cast<const f32x4*>(tab + 2 * MAXC + k);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[4 * i + q] = (valid && k + q < g.K) ? prelu(fmaf(xreg[i][q], sc[q], sh[q]), sl[q]) : 0.f;
+        }
+    };
+    float bias[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias[nt] = g.bias ? g.bias[nt * 32 + l31] : 0.f;
+    double s1[4], s2[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { s1[nt] = 0; s2[nt] = 0; }
+    __syncthreads();                                              // tab, stat
+    int t = blockIdx.x, kc = 0, buf = 0;
+    if (t < ntiles) {
+        issue(t, 0);
+        commit(t, 0, 0);
+    }
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+    while (t < ntiles) {
+        int nkc = kc + 1, nt_ = t;
+        if (nkc == nch) { nkc = 0; nt_ = t + gridDim.x; }
+        const bool more = nt_ < ntiles;
+        if (more) issue(nt_, nkc);
+        const float* wp = &ws[buf][l31 * WSF + lh * 32];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(wp + nt * 32 * WSF + 4 * j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * j + q], b[q], acc[nt], 0, 0, 0);
+            }
+        }
+        if (kc == nch - 1) {                                       // epilogue: bias, store, statistics
+            const long m0 = (long)t * 128 + wave * 32 + 4 * lh;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = nt * 32 + l31;
+                float f1 = 0.f, f2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long m = m0 + (e & 3) + 8 * (e >> 2);
+                    if (m < g.M) {
+                        const float o = acc[nt][e] + bias[nt];
+                        Out[m * g.ldo + g.n_off + n] = o;
+                        f1 += o; f2 += o * o;
+                    }
+                    acc[nt][e] = 0.f;
+                }
+                s1[nt] += f1; s2[nt] += f2;
+            }
+        }
+        if (more) commit(nt_, nkc, buf ^ 1);
+        __syncthreads();
+        if (!more) break;
+        t = nt_; kc = nkc; buf ^= 1;
+    }
+    if (g.part != nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            double x = s1[nt], y = s2[nt];
+            x += __shfl_xor(x, 32); y += __shfl_xor(y, 32);
+            if (lh == 0) { atomicAdd(&stat[(nt * 32 + l31) * 2], x); atomicAdd(&stat[(nt * 32 + l31) * 2 + 1], y); }
+        }
+        __syncthreads();
+        g.part[(long)blockIdx.x * 256 + tid] = stat[tid];
+    }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+bool conv1x1_fwd_f32_ok(const ConvFwdArgs& a) {
+    if (!conv3x3_tile_enabled() || a.mode != MODE_F32 || a.amode != A_1X1 || a.N != 128 || a.K > MAXC || a.K < 1 || (a.K & 3) || a.drop_p > 0.f) return false;
+    return aligned16(a.A) && aligned16(a.Wk) && (a.lda & 3) == 0 && (a.Kp & 3) == 0;
+}
+int conv1x1_fwd_f32_nblk(const ConvFwdArgs& a) {
+    const int ntiles = (a.M + 127) / 128;
+    return ntiles < 512 ? ntiles : 512;
+}
+int conv1x1_fwd_f32(const ConvFwdArgs& a, hipStream_t st) {
+    const int ntiles = (a.M + 127) / 128;
+    ProfScope ps("k_conv1x1_fwd_f32", 2.0 * a.M * (double)a.N * a.K, (double)a.M * 4.0 * (a.K + a.N), st);
+    constexpr size_t smem = 2 * 128 * WSF * 4;
+    static bool attr = false;
+    if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv1x1_fwd_f32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_conv1x1_fwd_f32, dim3(conv1x1_fwd_f32_nblk(a)), dim3(256), smem, st, a, ntiles, (a.K + 63) / 64);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
 
 bool conv1x1_dgrad_f32_ok(const ConvDgradArgs& a) {
     const EffSrc& e = a.e;

@@ -150,16 +150,23 @@ __global__ __launch_bounds__(NT) void k_conv_dgrad(const ConvDgradArgs g) {
                         const int ho = rem / g.W, wo = rem - ho * g.W;
                         const long p00 = ((long)img * g.Hin + 2 * ho) * g.Win + 2 * wo;
                         const float dA = 0.25f * acc[i][j][q];
+                        // the four pixels of the window: all loads in flight before the first use (a dependent load per pixel costs a
+                        // memory round trip each when few waves share the SIMD)
+                        float xv[4], gv[4];
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             const long px = p00 + (t >> 1) * g.Win + (t & 1);
-                            const float x = to_f<T>(Xin[px * g.ldxin + n]);
+                            xv[t] = to_f<T>(Xin[px * g.ldxin + n]);
+                            gv[t] = g.accumulate ? to_f<T>(Gout[px * g.ldgo + n]) : 0.f;
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const long px = p00 + (t >> 1) * g.Win + (t & 1);
+                            const float x = xv[t];
                             const float u = fmaf(x, sc, sh);
                             const float du = u > 0.f ? dA : sl * dA;
                             s1[j] += du; s2[j] += (double)du * x; s3[j] += u > 0.f ? 0.f : dA * u;
-                            T* o = Gout + px * g.ldgo + n;
-                            const float val = sc * du;
-                            *o = from_f<T>(g.accumulate ? to_f<T>(*o) + val : val);
+                            Gout[px * g.ldgo + n] = from_f<T>(gv[t] + sc * du);
                         }
                     } else {
                         const float x = to_f<T>(Xin[(long)m * g.ldxin + n]);

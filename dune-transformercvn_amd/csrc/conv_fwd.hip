@@ -169,6 +169,7 @@ int conv_fwd_grid(int M) {
 int conv_fwd_nblk(const ConvFwdArgs& a) {
     if (stem_fwd_ok(a)) return stem_fwd_nblk(a);
     if (conv3x3_fwd_f32_ok(a)) return conv3x3_fwd_f32_nblk(a);
+    if (conv1x1_fwd_f32_ok(a)) return conv1x1_fwd_f32_nblk(a);
     return conv3x3_tile_ok(a) ? conv3x3_tile_nblk(a) : conv_fwd_grid(a.M);
 }
 
@@ -179,6 +180,7 @@ int conv_fwd(const ConvFwdArgs& a, hipStream_t st) {
     if (stem_fwd_ok(a)) return stem_fwd_bf16(a, st);
     if (conv3x3_tile_ok(a)) return conv3x3_fwd_tile(a, st);
     if (conv3x3_fwd_f32_ok(a)) return conv3x3_fwd_f32(a, st);
+    if (conv1x1_fwd_f32_ok(a)) return conv1x1_fwd_f32(a, st);
     char nm[96];
     snprintf(nm, sizeof(nm), "k_conv_fwd<%s,%d,%d>", a.mode == MODE_F32 ? "float" : "bf16", a.amode, a.N <= 32 ? 32 : a.N <= 64 ? 64 : 128);
     ProfScope ps(nm, 2.0 * a.M * (double)a.N * a.K, (double)a.M * (a.mode == MODE_F32 ? 4.0 : 2.0) * (a.N + (a.amode == A_STEM ? 4.0 * a.C : a.amode == A_3X3 ? (double)a.C : (double)a.K)), st);

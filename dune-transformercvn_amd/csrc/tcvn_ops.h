@@ -146,6 +146,9 @@ bool conv3x3_dgrad_f32_ok(const ConvDgradArgs& a);
 int conv3x3_dgrad_f32_nblk(const ConvDgradArgs& a);
 int conv3x3_dgrad_f32(const ConvDgradArgs& a, hipStream_t st);
 // fp32 1x1 backward kernels (conv1x1_f32.hip): parity mode, Cin <= 512 -> 128 channels
+bool conv1x1_fwd_f32_ok(const ConvFwdArgs& a);
+int conv1x1_fwd_f32_nblk(const ConvFwdArgs& a);
+int conv1x1_fwd_f32(const ConvFwdArgs& a, hipStream_t st);
 bool conv1x1_dgrad_f32_ok(const ConvDgradArgs& a);
 int conv1x1_dgrad_f32_nblk(const ConvDgradArgs& a);
 int conv1x1_dgrad_f32(const ConvDgradArgs& a, hipStream_t st);
