@@ -113,6 +113,8 @@ int tcvn_sdxl_num_slots(const tcvn_sdxl* p);
 int tcvn_sdxl_slot(const tcvn_sdxl* p, int i, char* name, int name_cap, int64_t* numel, int* kind);
 int tcvn_sdxl_bind(tcvn_sdxl* p, void* const* data, void* const* grad);
 int64_t tcvn_sdxl_workspace_bytes(const tcvn_sdxl* p, int n_img, int with_backward);
+/* Same calling convention as tcvn_densenet_forward / _backward; `coords` must stay valid until tcvn_sdxl_backward has run (the
+ * conv_in weight gradient walks the hit list). */
 int tcvn_sdxl_forward(tcvn_sdxl* p, int n_img, const int32_t* coords, const float* values, int64_t nnz, int log_pixels,
                       float noise_std, float* out, int64_t out_ld, void* workspace, int64_t workspace_bytes, int train,
                       uint64_t seed, void* stream);
