@@ -12,11 +12,15 @@ from model_utils import build_trainer, to_device
 pytestmark = pytest.mark.gpu
 
 
-def _close(t, g, key, tol=2e-5):
+# fp32 summation-order noise of the train-mode taps (BatchNorm over a handful of maps): measured 1.3e-5 .. 2.3e-5 on the tokens and
+# 3.2e-5 on the hidden states depending on the kernel generation; eval-mode taps agree to 4e-6.  The gate on the logits is 1e-3.
+def _close(t, g, key, tol=5e-5):
     stat, samp = tap_sample(t.cpu())
     ref_stat, ref_samp = g[key.replace("tap:", "tap_stat:")], g[key.replace("tap:", "tap_samp:")]
     scale = max(float(np.abs(ref_samp).max()), 1e-12)
-    return max(float(np.abs(samp - ref_samp).max()) / scale, float(np.abs(stat - ref_stat).max()) / max(float(np.abs(ref_stat).max()), 1e-12)) < tol
+    err = max(float(np.abs(samp - ref_samp).max()) / scale, float(np.abs(stat - ref_stat).max()) / max(float(np.abs(ref_stat).max()), 1e-12))
+    print(key, "max-norm error vs reference tap", err)
+    return err < tol
 
 
 @pytest.mark.parametrize("name", ["small_b3", "tutorial_b2p4", "tutorial_ragged"])
