@@ -4,7 +4,9 @@ config 2: batch 32, 8 prongs/event, 3x400x280 maps) on N MI355X GPUs, one proces
 overlapped with backward.  Prints ONE JSON line (rank 0).
 
     python bench.py [--gpus 1 --steps 5 --warmup 2 --precision bf16]
+    python bench.py --gpus N ...            # starts its N ranks itself (one child process per GPU, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus 8 --global-batch 64      # strong scaling: the global batch is split over the ranks
 """
 import argparse
 import json
@@ -32,6 +34,37 @@ T0 = time.perf_counter()
 def note(msg):
     """progress line on stderr (rank 0 only prints the JSON on stdout)"""
     print(f"[bench +{time.perf_counter() - T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def launch_ranks(n):
+    """`--gpus N` without a launcher around us (reference: train.py:123-127 starts its ranks from num_gpu): this process -- which has
+    made NO GPU call yet -- starts N children of this same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, lets
+    rank 0 print the JSON line on the shared stdout, and exits with the worst child's code.  No process that touched the GPU is
+    ever re-executed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    pending = list(procs)
+    while pending:
+        for pr in list(pending):
+            rc = pr.poll()
+            if rc is None:
+                continue
+            pending.remove(pr)
+            if rc != 0:
+                worst = worst or rc
+                for other in pending:              # one rank failed: the others would wait in a collective forever
+                    other.terminate()
+        time.sleep(0.2)
+    return worst
 
 
 def host_threads():
@@ -129,7 +162,18 @@ def cpu_baseline(threads, prongs):
     ts.sort()
     note(f"cpu baseline: {cpu_model()}, os.cpu_count()={os.cpu_count()}, threads used {threads}, torch threads "
          f"{torch.get_num_threads()}, warm-up {warm:.2f} s, steps {[round(t, 2) for t in ts]} s")
+    # SURVEY.md 8(d)'s config-1 shape beside it (the reference's own CPU-runnable case): B = 2, 4 prongs, 2-layer encoder
+    cfg1 = O.tutorial_config(num_encoder_layers=2)
+    sd1 = O.fill_state(cfg1, 1)
+    b1 = O.synthetic_batch([4, 4], 11, cfg1)
+    O.train_step(sd1, cfg1, b1, apply_dropout=True)
+    t0 = time.perf_counter()
+    O.train_step(sd1, cfg1, b1, apply_dropout=True)
+    c1 = 2 / (time.perf_counter() - t0)
+    note(f"cpu baseline, config-1 shape (2 events x 4 prongs, 2-layer encoder): {c1:.2f} events/s")
     return {"value": round(ev / ts[len(ts) // 2], 3), "unit": "events/s", "cores": threads, "kind": "port",
+            "config1_shape_value": round(c1, 3),
+            "config1_shape_sample": "oracle fp32 fwd+loss+bwd, 2 events x 4 prongs (10 maps), 2-layer encoder, 1 step after 1 warm-up",
             "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(),
             "sample": f"oracle fp32 fwd+loss+bwd, {ev} events x {prongs} prongs ({ev * (1 + prongs)} maps), 6-layer encoder, dropout 0.1, "
                       f"median of {len(ts)} steps after 1 warm-up"}
@@ -146,6 +190,32 @@ def fp32_parity_mode_ms(opt_path, args, dev, batch):
     model = NeutrinoFullDenseTrainer(opt).to(dev)
     model.train()
     rt = model.network.hip_runtime()
+
+    def step():
+        rt.zero_grad()
+        model.training_step(batch, 0).backward()
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    return 1000 * (time.perf_counter() - t0) / 2
+
+
+def sdxl_mode_ms(opt_path, args, dev):
+    """ms/step of BASELINE config 4 (--sdxl embedder, batch 16 x 8 prongs, bf16; parity unpinned: diffusers is not available) so that the
+    default run puts it on the driver's record: 1 warm-up + 2 timed steps."""
+    from transformercvn.options import Options
+    from transformercvn.network.trainers.neutrino_full_sdxl_trainer import NeutrinoFullSDXLTrainer
+    opt = Options.load(opt_path)
+    opt.batch_size, opt.num_gpu, opt.hip_precision, opt.seed = 16, 1, "bf16", 1234
+    opt.training_file = "synthetic:64:8"
+    torch.manual_seed(0)
+    model = NeutrinoFullSDXLTrainer(opt).to(dev)
+    model.train()
+    rt = model.network.hip_runtime()
+    batch = make_batch(16, 8, 1234, dev)
 
     def step():
         rt.zero_grad()
@@ -183,7 +253,10 @@ def main():
     ap.add_argument("--sdxl", action="store_true", help="BASELINE config 4: the SDXL-style embedder (train.py --sdxl), batch 16")
     ap.add_argument("--ragged-inference", action="store_true",
                     help="BASELINE config 5: eval-mode forward only, 1..16 prongs per event (packed attention mask)")
-    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="events per GPU (weak scaling; default 32, 16 with --sdxl)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="strong scaling: total events per step, split evenly over the ranks (north star: 64 at 8 GPUs)")
+    ap.add_argument("--no-sdxl", action="store_true", help="skip the --sdxl (config 4) timing of the default run (sdxl_ms_per_step)")
     ap.add_argument("--prongs", type=int, default=8)
     ap.add_argument("--dropout", type=float, default=None, help="override options.dropout (experiments only; the metric uses the file's 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -193,12 +266,20 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing (fp32_ms_per_step)")
     ap.add_argument("--dump-records", default="", help="write every profiled launch (name, ms, flops) to this JSON file")
     args = ap.parse_args()
-    if args.batch is None:
-        args.batch = 16 if args.sdxl else 32
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # no launcher around us: start the ranks (no GPU call so far)
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line's n_gpus would not be what was asked for")
+    strong = args.global_batch is not None
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of {world} ranks")
+        args.batch = args.global_batch // world
+    if args.batch is None:
+        args.batch = 16 if args.sdxl else 32
     # rehearsal on a one-GPU box (control flow of the multi-rank path only): TCVN_BENCH_REHEARSAL=1 puts every rank on
     # cuda:0 and exchanges over gloo; the real run is one rank per GPU over RCCL ("nccl")
     rehearsal = os.environ.get("TCVN_BENCH_REHEARSAL") == "1"
@@ -217,7 +298,9 @@ def main():
     if args.sdxl:
         from transformercvn.network.trainers.neutrino_full_sdxl_trainer import NeutrinoFullSDXLTrainer as NeutrinoFullDenseTrainer
     from transformercvn.hip import _lib
-    from transformercvn.hip.distributed import GradReducer, broadcast_buffers
+    from transformercvn.hip.distributed import broadcast_buffers
+    if os.path.basename(_lib.LIB_PATH) != "libtcvn_hip.so":
+        raise SystemExit(f"bench.py measures the product library only, not {_lib.LIB_PATH}")
 
     opt_path = os.path.join(PKG, "option_files", "tutorial_densenet_synthetic.json")
     opt = Options.load(opt_path)
@@ -225,8 +308,8 @@ def main():
     opt.training_file = f"synthetic:64:{args.prongs}"
     if args.dropout is not None:
         opt.dropout = args.dropout
-    torch.manual_seed(0)                                            # identical random-init weights on every rank
-    model = NeutrinoFullDenseTrainer(opt).to(dev)
+    torch.manual_seed(rank)              # every rank draws its own initial weights; enable_data_parallel() broadcasts rank 0's (as DDP does
+    model = NeutrinoFullDenseTrainer(opt).to(dev)      # for the reference, whose train.py sets no seed)
     model.train()
     rt = model.network.hip_runtime()
     if args.side_priority is not None:
@@ -237,9 +320,7 @@ def main():
     batch = make_batch(args.batch, (1, 16) if args.ragged_inference else args.prongs, 1234 + rank, dev)
     if args.ragged_inference:
         model.eval()
-    reducer = GradReducer(rt.flat_grad, rt.segments) if world > 1 else None
-    if reducer:
-        rt.grad_ready_hook = reducer.on_ready
+    reducer = model.enable_data_parallel() if world > 1 else None    # state broadcast from rank 0 + overlapped arena all-reduce hooks
 
     def step():
         if args.ragged_inference:                 # inference only: no loss, no backward, no exchange (embarrassingly parallel)
@@ -366,7 +447,7 @@ def main():
                       "events/sec (fwd+bwd) at batch=32, 8 prongs/event; fraction of MFMA roofline" if not args.sdxl else
                       "events/sec (fwd+bwd) at batch=16, 8 prongs/event, --sdxl embedder; fraction of MFMA roofline",
             "value": round(value, 2), "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1000 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": (f"TransformerCVN DenseNet [3,6,12,6,3] g32, eval-mode forward only, batch {args.batch}/GPU, ragged "
                                     f"1-16 prongs/event ({n_maps - args.batch} prong maps in this batch), 3x400x280 maps, 6-layer encoder")
@@ -379,6 +460,7 @@ def main():
             "model_tflops_per_gpu": round(per_gpu_tflops, 2),
             "frac_of_mfma_peak_whole_step": round(per_gpu_tflops / PEAK[args.precision], 4),
             "loss": round(lossv, 5),
+            "library": os.path.basename(_lib.LIB_PATH),
         }
         if roof:
             out["roofline"] = roof
@@ -389,6 +471,14 @@ def main():
             torch.cuda.empty_cache()
             out["fp32_ms_per_step"] = round(fp32_parity_mode_ms(opt_path, args, dev, batch), 2)
             out["fp32_events_per_s"] = round(args.batch / out["fp32_ms_per_step"] * 1000, 1)
+        if args.precision == "bf16" and world == 1 and not args.no_sdxl and not args.sdxl and not args.ragged_inference and not strong:
+            note("--sdxl embedder, config 4 (1 warm-up + 2 steps) ...")
+            model = rt = None
+            torch.cuda.empty_cache()
+            out["sdxl_ms_per_step"] = round(sdxl_mode_ms(opt_path, args, dev), 2)
+            out["sdxl_events_per_s"] = round(16 / out["sdxl_ms_per_step"] * 1000, 1)
+            out["sdxl_note"] = "BASELINE config 4: batch 16 x 8 prongs, bf16, fwd+loss+bwd; parity of this embedder is unpinned (diffusers absent)"
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1 and not args.sdxl and not args.ragged_inference:       # rank 0 at N=1 only (DenseNet workload)
             note("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline(host_threads(), args.prongs)

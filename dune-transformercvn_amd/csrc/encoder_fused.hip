@@ -526,10 +526,12 @@ int launch_fwd(const EncFusedArgs& a, hipStream_t st) {
     constexpr int SP = 2 * NR, H = D / HD;
     const size_t smem = ((size_t)D * WLD + (size_t)SP * (5 * D + QLD)) * 4 + SMAX * 4 + 64;
     if (H * a.S * (a.S + 1) > 2 * SP * D) return -2;
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[16] = {};                  // per device: the attribute belongs to the device's copy of the function
+    int dev = 0;
+    TCVN_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16 || !attr[dev]) {
         TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_fwd<HD, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        if (dev >= 0 && dev < 16) attr[dev] = true;
     }
     if (smem > 160 * 1024) return -2;
     hipLaunchKernelGGL((k_encoder_fwd<HD, NR>), dim3(a.B), dim3(256), smem, st, a);
@@ -540,10 +542,12 @@ template <int HD, int NR>
 int launch_bwd(const EncFusedBwdArgs& a, hipStream_t st) {
     constexpr int SP = 2 * NR;
     const size_t smem = ((size_t)HR * WLD + (size_t)SP * (4 * D + 2 * QLD)) * 4 + 64;
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[16] = {};
+    int dev = 0;
+    TCVN_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16 || !attr[dev]) {
         TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_bwd<HD, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        if (dev >= 0 && dev < 16) attr[dev] = true;
     }
     if (smem > 160 * 1024) return -2;
     hipLaunchKernelGGL((k_encoder_bwd<HD, NR>), dim3(a.B), dim3(256), smem, st, a);
@@ -553,8 +557,16 @@ int launch_bwd(const EncFusedBwdArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// Every condition the launchers below depend on: a shape this returns true for is never rejected later (the callers pick the
+// layer-by-layer kernels on false; there is no fallback after a launch has been attempted).
 bool encoder_fused_ok(int S, int Dm, int H, int L, int norm_first) {
-    return Dm == D && (H == 4 || H == 8) && S >= 1 && S <= SMAX && L >= 1 && L <= ENC_MAX_LAYERS && !norm_first;
+    if (!(Dm == D && (H == 4 || H == 8) && S >= 1 && S <= SMAX && L >= 1 && L <= ENC_MAX_LAYERS && !norm_first)) return false;
+    const int SP = 2 * rows_bucket(S);
+    if ((long)H * S * (S + 1) > 2L * SP * D) return false;                          // score rows alias the token buffers (forward)
+    if (2L * H * SMAX * (SMAX + 1) > (long)HR * WLD) return false;                  // dS / dropped-P exchange aliases the weight image (backward)
+    const size_t smem_f = ((size_t)D * WLD + (size_t)SP * (5 * D + QLD)) * 4 + SMAX * 4 + 64;
+    const size_t smem_b = ((size_t)HR * WLD + (size_t)SP * (4 * D + 2 * QLD)) * 4 + 64;
+    return smem_f <= 160 * 1024 && smem_b <= 160 * 1024;
 }
 
 int encoder_fused_fwd(const EncFusedArgs& a, hipStream_t st) {

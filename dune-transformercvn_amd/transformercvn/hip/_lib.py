@@ -11,10 +11,13 @@ import os
 import torch  # noqa: F401  -- first: the library must bind to the HIP runtime PyTorch ships (one runtime per process); loading
 #                              /opt/rocm's copy ahead of torch's leaves this library without a device ("no ROCm-capable device")
 
+from . import _libselect
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# TCVN_HIP_LIBRARY names another build in the same directory -- only the variant tests use it, to load libtcvn_hip_dbg.so
-# (the -DTCVN_DEBUG_KNOBS build that honours the validation switches) in a child process.
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", os.path.basename(os.environ.get("TCVN_HIP_LIBRARY", "libtcvn_hip.so"))))
+# libtcvn_hip.so unless a test child process selected the debug build explicitly (_libselect.use) before this import; no
+# environment variable is read here or in the product library.
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", _libselect.NAME))
+_libselect._bound = True
 
 MODE_F32, MODE_BF16 = 0, 1
 SLOT_PARAM, SLOT_BUFFER, SLOT_COUNTER = 0, 1, 2

@@ -108,11 +108,13 @@ class NeutrinoBaseNetwork(nn.Module):
         self.pixel_shape: Tuple[int, int] = (400, 280)
 
     def hip_runtime(self):
-        """Lazily created fused runtime (precision from ``options.hip_precision``: 'fp32' parity mode or 'bf16')."""
+        """Lazily created fused runtime.  Precision: ``options.hip_precision`` ('fp32' parity mode or 'bf16') or, when the option
+        file does not name it, what the Lightning trainer was given (``train.py -fp16`` -> precision 16 -> bf16 engines; see
+        NeutrinoFullBaseTrainer.adopt_trainer_precision)."""
         if self._runtime is None:
             from transformercvn.hip.runtime import HipRuntime
-            self._runtime = HipRuntime(self, self._options, self.pixel_shape, getattr(self._options, "hip_precision", "fp32"),
-                                       seed=int(getattr(self._options, "seed", 0)))
+            precision = getattr(self, "_precision_override", None) or getattr(self._options, "hip_precision", "fp32")
+            self._runtime = HipRuntime(self, self._options, self.pixel_shape, precision, seed=int(getattr(self._options, "seed", 0)))
         return self._runtime
 
     def forward(self, features: Tensor, extra: Tensor, event_pixels: Tensor, event_mask: Tensor, prong_pixels: Tensor,

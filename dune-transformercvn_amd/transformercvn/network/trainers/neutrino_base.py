@@ -95,11 +95,24 @@ class NeutrinoBase(_Base):
         return self.dataloader(self.testing_dataset, **self.dataloader_options)
 
     # ---- optimisation ----------------------------------------------------------------------------------------------
+    def configure_gradient_clipping(self, optimizer, *args, **kwargs):
+        """Lightning hook (train.py:140 passes gradient_clip_val to the Trainer): with the fused optimizer the global-norm clip is one
+        reduction over the gradient arena inside FlatAdamW.step (same `gradient_clip` value), so Lightning's 782-tensor
+        clip_grad_norm_ in front of it is skipped; any other optimizer keeps Lightning's clipping."""
+        flat = getattr(self, "_flat_optimizer", None)
+        if flat is not None and optimizer is flat and flat.clip > 0:
+            return
+        parent = getattr(super(), "configure_gradient_clipping", None)
+        if parent is not None:
+            return parent(optimizer, *args, **kwargs)
+
     def configure_optimizers(self):
         """AdamW-style optimizer with two parameter groups and a per-step LambdaLR (:88-152).  The no-decay group is
         selected by the substrings 'bias' / 'LayerNorm.weight' in the parameter name -- as in the reference the second
         string never matches torch's norm names, so norm and PReLU weights are decayed."""
         o = self.options
+        if hasattr(self, "adopt_trainer_precision"):
+            self.adopt_trainer_precision()                   # before the optimizer binds the parameter arena
         opt_cls = None
         if "apex" in o.optimizer:
             try:
@@ -126,6 +139,7 @@ class NeutrinoBase(_Base):
             names = {id(p): n[len("network."):] for n, p in named if n.startswith("network.")}
             frozen = ["prong_position_embedding"] + (["feature_embedding."] if o.disable_smart_features else [])
             optimizer = FlatAdamW(groups, rt, names, lr=o.learning_rate, clip=o.gradient_clip, frozen=frozen)
+            self._flat_optimizer = optimizer           # enable_data_parallel() broadcasts its moments from rank 0 (resume)
         if optimizer is None:
             optimizer = opt_cls(groups, lr=o.learning_rate)
         if o.learning_rate_cycles < 1:

@@ -66,18 +66,56 @@ class NeutrinoFullBaseTrainer(NeutrinoBase, ABC):
     def enable_data_parallel(self, group=None):
         """Install the overlapped arena all-reduce (RCCL via torch.distributed) on the runtime's segment hooks.  Called by
         on_fit_start() under Lightning; custom loops (bench.py) call it after init_process_group.  No-op at world size 1."""
-        import torch.distributed as dist
+        from transformercvn.hip import distributed as hd
         from transformercvn.hip.distributed import GradReducer
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        if not hd._active(group):
             return None
         rt = self.network.hip_runtime()
         rt.ensure_bound()
+        # the ranks may have started from different random weights (the reference sets no seed and relies on DDP's initial
+        # broadcast, which here covers the anchor only): rank 0's parameters, BatchNorm buffers and optimizer moments everywhere
+        from transformercvn.hip.distributed import sync_state
+        sync_state(rt, getattr(self, "_flat_optimizer", None), group)
         self._reducer = GradReducer(rt.flat_grad, rt.segments, group)
         rt.grad_ready_hook = self._reducer.on_ready
         self._dp_group = group
         return self._reducer
 
+    # ---- precision (reference: train.py:141,172  `-fp16` -> pl.Trainer(precision=16 if fp16 else 32)) ------------------
+    def adopt_trainer_precision(self):
+        """Lightning precision 16 / "16-mixed" / "bf16" selects the bf16 MFMA engines (the throughput mode), 32 the fp32 parity
+        engines -- unless the option file names `hip_precision` itself.  Lightning's AMP plugin may still wrap the step in
+        autocast and scale the loss: all arithmetic here is in libtcvn_hip.so with explicit types, the scaled loss gradient
+        scales the arena linearly, and GradScaler.unscale_ works on the arena views (tests/test_optimizer_gpu.py)."""
+        if "hip_precision" in vars(self.options):
+            return
+        try:
+            prec = getattr(self, "trainer", None)
+            prec = None if prec is None else getattr(prec, "precision", None)
+        except Exception:                                   # pl.LightningModule.trainer raises while unattached
+            prec = None
+        if prec is None:
+            return
+        want = "bf16" if str(prec).replace("-mixed", "").replace("-true", "") in ("16", "bf16") else "fp32"
+        self.set_precision(want, from_options=False)
+
+    def set_precision(self, precision: str, from_options: bool = True):
+        from transformercvn.hip.runtime import PRECISIONS
+        mode = PRECISIONS[str(precision).lower()]
+        net = self.network
+        if from_options:
+            self.options.hip_precision = precision
+        net._precision_override = precision
+        if net._runtime is not None and net._runtime.mode != mode:
+            if getattr(self, "_flat_optimizer", None) is not None:
+                raise RuntimeError("precision change after configure_optimizers(): the parameter arena would be rebuilt under the optimizer")
+            net._runtime = None                              # engines are rebuilt (and the arenas re-bound) on the next call
+
+    def setup(self, stage=None):
+        self.adopt_trainer_precision()
+
     def on_fit_start(self):
+        self.adopt_trainer_precision()
         self.enable_data_parallel()
 
     def on_train_batch_start(self, batch, batch_idx, *args):

@@ -249,6 +249,10 @@ def main():
     run_case("tutorial_b2p4", dict(num_encoder_layers=2), [4, 4], batch_seed=11, weight_seed=1)
     # ragged batch, full 6-layer encoder (config 5 shape): 1..16 prongs
     run_case("tutorial_ragged", dict(), [1, 16, 5], batch_seed=12, weight_seed=2)
+    # BASELINE config 2's own token shape: 8 prongs/event (S = 9: the <16,5> instantiation of the fused encoder), 6-layer encoder
+    run_case("tutorial_b2p8", dict(), [8, 8], batch_seed=14, weight_seed=4)
+    # 12 prongs/event (S = 13: the <16,8> instantiation; the middle of config 5's ragged range)
+    run_case("tutorial_b2p12", dict(), [12, 12], batch_seed=15, weight_seed=5)
     # reduced network for fast layer-by-layer debugging
     run_case("small_b3", dict(densenet_structure=[2, 2], densenet_growth_rate=8, initial_pixel_dim=16,
                               num_encoder_layers=2, pixel_embedding_dim=64, hidden_dim=64,

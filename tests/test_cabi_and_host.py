@@ -38,6 +38,15 @@ def test_product_library_has_no_environment_switches():
     blob = open(_lib.LIB_PATH, "rb").read()
     for knob in (b"TCVN_DBG", b"TCVN_DISABLE_TILE", b"TCVN_XA_ONTHEFLY", b"TCVN_BWD_SERIAL", b"TCVN_POOL0_BWD_FLAT"):
         assert knob not in blob, knob
+    # ... and the Python loader binds the product library whatever the environment says (the debug build is selected only by an
+    # explicit _libselect.use() call in a test child process)
+    import sys
+    code = ("import sys; sys.path[:0] = %r\nfrom transformercvn.hip import _lib\nimport os\nprint(os.path.basename(_lib.LIB_PATH))" % (sys.path,))
+    env = dict(os.environ, TCVN_HIP_LIBRARY="libtcvn_hip_dbg.so", TCVN_DISABLE_TILE="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, check=True).stdout.strip()
+    assert out == "libtcvn_hip.so", out
+    src = open(_lib.__file__).read() + open(_lib._libselect.__file__).read()
+    assert "os.environ" not in src and "getenv" not in src
 
 
 def test_densenet_plan_slots_match_reference_layout():
@@ -166,3 +175,22 @@ def test_device_feeder_cpu_passthrough_attaches_host_counts():
         assert got[10] == (int(src[7].sum(1).max()), int(src[7].sum()))
         for a, b in zip(src[:10], got[:10]):
             assert torch.equal(a, b)
+
+
+def test_lightning_precision_16_selects_the_bf16_engines():
+    """train.py -fp16 -> pl.Trainer(precision=16) (reference train.py:141,172): the drop-in module maps the trainer's precision to its
+    engines unless the option file names hip_precision itself."""
+    from types import SimpleNamespace
+    from model_utils import build_trainer
+    from transformercvn.hip import _lib
+    cfg = O.tutorial_config(densenet_structure=[1, 1], densenet_growth_rate=8, initial_pixel_dim=16, num_encoder_layers=1)
+    for prec, mode in ((16, _lib.MODE_BF16), ("16-mixed", _lib.MODE_BF16), ("bf16", _lib.MODE_BF16), (32, _lib.MODE_F32), ("32-true", _lib.MODE_F32)):
+        m = build_trainer(cfg, None, device=None)
+        del m.options.hip_precision                         # option file silent about it (the reference's files are)
+        m.trainer = SimpleNamespace(precision=prec)
+        m.setup("fit")
+        assert m.network.hip_runtime().mode == mode, prec
+    m = build_trainer(cfg, None, precision="fp32", device=None)      # an explicit option wins over the trainer
+    m.trainer = SimpleNamespace(precision=16)
+    m.setup("fit")
+    assert m.network.hip_runtime().mode == _lib.MODE_F32

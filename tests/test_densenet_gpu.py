@@ -180,9 +180,8 @@ def test_bf16_tile_kernels_match_generic_kernels(name, monkeypatch):
     n_img = int(batch[7].sum())
     d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
     out, taps, grads = _run_bf16(cfg, sd, batch, True, d_out)
-    code = f"""
-import sys, torch
-sys.path[:0] = {sys.path!r}
+    from variant_utils import run_on_debug_build
+    ref = run_on_debug_build(f"""
 import test_densenet_gpu as T
 from oracle import tcvn_oracle as O
 from golden_utils import load_case, train_cfg
@@ -192,11 +191,8 @@ sd = O.fill_state(cfg, int(g['weight_seed']))
 n_img = int(batch[7].sum())
 d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
 out, taps, grads = T._run_bf16(cfg, sd, batch, True, d_out)
-torch.save(dict(out=out, taps=taps, grads=grads), {('/tmp/tcvn_generic_' + name + '.pt')!r})
-"""
-    env = dict(os.environ, TCVN_DISABLE_TILE="1", TCVN_HIP_LIBRARY="libtcvn_hip_dbg.so")
-    subprocess.check_call([sys.executable, "-c", code], env=env)
-    ref = torch.load("/tmp/tcvn_generic_" + name + ".pt")
+result = dict(out=out, taps=taps, grads=grads)
+""", dict(TCVN_DISABLE_TILE="1"))
     e_out = ((out - ref["out"]).norm() / ref["out"].norm()).item()
     per_tap = {k: ((taps[k] - ref["taps"][k]).norm() / ref["taps"][k].norm()).item() for k in taps}
     print("per block", per_tap)
@@ -235,9 +231,8 @@ def test_fp32_tile_kernels_match_generic_kernels():
     n_img = int(batch[7].sum())
     d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
     out, taps, grads = _run_bf16(cfg, sd, batch, True, d_out, mode=0)
-    code = f"""
-import sys, torch
-sys.path[:0] = {sys.path!r}
+    from variant_utils import run_on_debug_build
+    ref = run_on_debug_build("""
 import test_densenet_gpu as T
 from oracle import tcvn_oracle as O
 from golden_utils import train_cfg
@@ -247,11 +242,8 @@ sd = O.fill_state(cfg, int(g['weight_seed']))
 n_img = int(batch[7].sum())
 d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
 out, taps, grads = T._run_bf16(cfg, sd, batch, True, d_out, mode=0)
-torch.save(dict(out=out, taps=taps, grads=grads), '/tmp/tcvn_generic_f32_mid.pt')
-"""
-    env = dict(os.environ, TCVN_DISABLE_TILE="1", TCVN_HIP_LIBRARY="libtcvn_hip_dbg.so")
-    subprocess.check_call([sys.executable, "-c", code], env=env)
-    ref = torch.load("/tmp/tcvn_generic_f32_mid.pt")
+result = dict(out=out, taps=taps, grads=grads)
+""", dict(TCVN_DISABLE_TILE="1"))
     e_out = ((out - ref["out"]).norm() / ref["out"].norm()).item()
     e_tap = max(((taps[k] - ref["taps"][k]).norm() / ref["taps"][k].norm()).item() for k in taps)
     errs = []
@@ -276,9 +268,8 @@ def test_bf16_fallback_variants_match_default_variants():
     n_img = int(batch[7].sum())
     d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
     out, taps, grads = _run_bf16(cfg, sd, batch, True, d_out)
-    code = f"""
-import sys, torch
-sys.path[:0] = {sys.path!r}
+    from variant_utils import run_on_debug_build
+    ref = run_on_debug_build("""
 import test_densenet_gpu as T
 from oracle import tcvn_oracle as O
 from golden_utils import train_cfg
@@ -288,11 +279,8 @@ sd = O.fill_state(cfg, int(g['weight_seed']))
 n_img = int(batch[7].sum())
 d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(5))
 out, taps, grads = T._run_bf16(cfg, sd, batch, True, d_out)
-torch.save(dict(out=out, taps=taps, grads=grads), '/tmp/tcvn_fallback_mid.pt')
-"""
-    env = dict(os.environ, TCVN_DBG="32", TCVN_POOL0_BWD_FLAT="1", TCVN_HIP_LIBRARY="libtcvn_hip_dbg.so")
-    subprocess.check_call([sys.executable, "-c", code], env=env)
-    ref = torch.load("/tmp/tcvn_fallback_mid.pt")
+result = dict(out=out, taps=taps, grads=grads)
+""", dict(TCVN_DBG="32", TCVN_POOL0_BWD_FLAT="1"))
     e_out = ((out - ref["out"]).norm() / ref["out"].norm()).item()
     e_tap = max(((taps[k] - ref["taps"][k]).norm() / ref["taps"][k].norm()).item() for k in taps)
     k0 = "features.conv0.weight"

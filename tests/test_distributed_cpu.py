@@ -85,7 +85,9 @@ def _runtime_worker(rank, world, port, ret):
         return min(offs[k][0] for k in ks), max(offs[k][0] + offs[k][1] for k in ks)
     total = sum(sizes)
     rt.flat_grad = torch.zeros(total)
-    rt.flat_param = torch.zeros(total)
+    torch.manual_seed(100 + rank)                           # every rank starts from DIFFERENT random weights (the reference's train.py
+    rt.flat_param = torch.randn(total)                      # sets no seed and relies on DDP's construction-time broadcast)
+    rt.flat_nbt = torch.full((7,), rank, dtype=torch.int64)
     rt.flat_buf = torch.full((64,), float(rank))
     rt.segments = {"prong": span("prong_embedding.prong_pixel_embedding."), "event": span("prong_embedding.event_pixel_embedding.")}
     rt._needs_rebind = lambda: False
@@ -99,6 +101,15 @@ def _runtime_worker(rank, world, port, ret):
     rt.pr_engine = _FakeEngine(rt.flat_grad, rt.segments["prong"], float(2 * rank + 1))
     order = []
     assert model.enable_data_parallel() is not None and rt.grad_ready_hook is not None
+
+    def same_on_all_ranks(t):
+        got = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        return all(torch.equal(got[0], x) for x in got)
+    # on_fit_start's state sync: rank 0's parameters, buffers and counters everywhere
+    torch.manual_seed(100)
+    synced = torch.equal(rt.flat_param, torch.randn(total)) and same_on_all_ranks(rt.flat_param)
+    synced = synced and bool((rt.flat_nbt == 0).all()) and bool((rt.flat_buf == 0).all())
     inner = rt.grad_ready_hook
     rt.grad_ready_hook = lambda tag: (order.append(tag), inner(tag))
     model.on_train_batch_start(None, 0)                     # buffer broadcast from rank 0
@@ -107,7 +118,9 @@ def _runtime_worker(rank, world, port, ret):
     model.on_after_backward()                               # waits for the segment exchanges
     mean_scale = sum(r + 1 for r in range(world)) / world
     mean_scale_pr = sum(2 * r + 1 for r in range(world)) / world
-    ok = order == ["head", "event", "prong"] and bool((rt.flat_buf == 0).all())
+    ok = synced and order == ["head", "event", "prong"] and bool((rt.flat_buf == 0).all())
+    rt.flat_param -= 0.1 * rt.flat_grad                     # one optimizer step on the averaged gradients: the ranks stay identical
+    ok = ok and same_on_all_ranks(rt.flat_param)
     for lo, hi in plan["head"]:
         ok = ok and torch.allclose(rt.flat_grad[lo:hi], torch.full((hi - lo,), mean_scale))
     lo, hi = rt.segments["event"]

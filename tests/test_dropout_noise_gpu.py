@@ -71,10 +71,30 @@ def _noise_from_map(eng, coords, values, std):
     return (got / (values / 255.0) - 1.0) / std
 
 
-def test_dropout_masks_and_noise_replayed_in_oracle_fp32():
+def _replay_case(which):
+    """small_b3: the committed golden's batch (hidden 64: layer-by-layer encoder kernels).  hidden128_p8: the same small DenseNets under
+    the tutorial token path -- hidden 128, 6 layers, 8 prongs/event (S = 9) -- i.e. the FUSED encoder kernels (csrc/encoder_fused.hip,
+    row bucket <16,5>: BASELINE config 2's instantiation) with their LDS dropout masks.  hidden128_p12: S = 13, bucket <16,8>.
+    norm_first: the pre-norm branch (layer-by-layer kernels) with dropout > 0."""
     cfg, over, batch, g = load_case("small_b3")                  # dropout 0.1, pixel_noise_std 0.001 (tutorial values)
+    if which == "small_b3":
+        return cfg, batch, int(g["weight_seed"])
+    over = dict(over)
+    if which == "norm_first":
+        over.update(transformer_norm_first=True)
+        prongs = [2, 5, 3]
+    else:
+        over.update(hidden_dim=128, num_encoder_layers=6, num_prong_decoder_layers=4)
+        prongs = [8, 8, 8] if which == "hidden128_p8" else [12, 9, 12, 11]
+    cfg = O.tutorial_config(**over)
+    return cfg, O.synthetic_batch(prongs, 31, cfg), 7
+
+
+@pytest.mark.parametrize("which", ["small_b3", "hidden128_p8", "hidden128_p12", "norm_first"])
+def test_dropout_masks_and_noise_replayed_in_oracle_fp32(which):
+    cfg, batch, wseed = _replay_case(which)
     assert cfg.dropout == 0.1 and cfg.pixel_noise_std == 0.001
-    sd = O.fill_state(cfg, int(g["weight_seed"]))
+    sd = O.fill_state(cfg, wseed)
     model = build_trainer(cfg, sd)
     model.train()
     rt = model.network.hip_runtime()

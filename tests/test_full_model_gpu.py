@@ -12,7 +12,9 @@ from test_oracle_golden import grad_close, is_noise_grad
 pytestmark = pytest.mark.gpu
 
 LOGIT_GATE = 1e-3          # BASELINE.json north_star
-CASES = ["small_b3", "tutorial_b2p4", "tutorial_ragged"]
+# b2p8 / b2p12: hidden 128, 6-layer encoder, S = 9 / 13 -> the <16,5> and <16,8> row buckets of csrc/encoder_fused.hip (the ones
+# BASELINE config 2 and the middle of config 5's ragged range run); ragged: S = 17 -> <16,11>; b2p4: S = 5 -> <16,3>
+CASES = ["small_b3", "tutorial_b2p4", "tutorial_ragged", "tutorial_b2p8", "tutorial_b2p12"]
 
 
 def _loaded_so():
@@ -66,11 +68,11 @@ def test_train_step_matches_reference(name):
             continue
         l2 = ((mine - ref).norm() / ref.norm()).item()
         worst = max(worst, l2)
-        assert l2 < (2e-2 if deep else 2e-3), (k, l2)
+        assert l2 < (1e-2 if deep else 2e-3), (k, l2)
     print(name, "worst relative L2 gradient error vs fp64 oracle", worst)
     # golden (reference fp32) sentinels with the fp32 noise band
     for k in [k for k in g if k.startswith("grad:")]:
-        assert grad_close(k[5:], named[k[5:]].grad.cpu().numpy(), g[k], rtol=5e-2 if deep else 6e-3), k
+        assert grad_close(k[5:], named[k[5:]].grad.cpu().numpy(), g[k], rtol=2e-2 if deep else 6e-3), k
     # BatchNorm running statistics after the step
     msd = model.state_dict()
     for k in [k for k in g if k.startswith("newstat:")]:

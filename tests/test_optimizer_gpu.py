@@ -78,3 +78,46 @@ def test_trainer_builds_the_fused_optimizer_and_steps():
     assert torch.isfinite(rt.flat_param).all()
     sd = opt.state_dict()
     assert sd["flat"]["step"] == 1 and sd["flat"]["exp_avg"].numel() == rt.flat_param.numel()
+
+
+def test_amp_grad_scaler_flow_on_the_arena_views():
+    """`train.py -fp16` runs the step under Lightning's AMP plugin: autocast around training_step, the loss scaled by a GradScaler,
+    unscale_ + inf check on every parameter's .grad, then optimizer.step().  Gradients here live in one arena and never pass through
+    autograd: the scaled loss gradient must scale the arena linearly, unscale_ must bring it back, and the scaler must step the
+    fused optimizer."""
+    from model_utils import build_trainer, to_device
+    from golden_utils import load_case, train_cfg
+    cfg, over, batch, g = load_case("small_b3")
+    cfg = train_cfg(over)
+    sd = O.fill_state(cfg, int(g["weight_seed"]))
+    dbatch = to_device(batch)
+    ref = build_trainer(cfg, sd, "bf16")
+    ref.train()
+    rt0 = ref.network.hip_runtime()
+    rt0.zero_grad()
+    ref.training_step(dbatch, 0).backward()
+    torch.cuda.synchronize()
+    plain = rt0.flat_grad.clone()
+
+    model = build_trainer(cfg, sd, "bf16")
+    model.train()
+    (opt,), _ = model.configure_optimizers()
+    for grp in opt.param_groups:
+        grp["lr"] = 1e-3
+    rt = model.network.hip_runtime()
+    scaler = torch.cuda.amp.GradScaler(init_scale=1024.0)
+    rt.zero_grad()
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss = model.training_step(dbatch, 0)
+    scaler.scale(loss).backward()
+    torch.cuda.synchronize()
+    e = ((rt.flat_grad / 1024.0 - plain).norm() / plain.norm()).item()
+    print("scaled backward / 1024 vs plain backward: rel L2", e)
+    assert e < 1e-5
+    scaler.unscale_(opt)
+    assert ((rt.flat_grad - plain).norm() / plain.norm()).item() < 1e-5
+    before = rt.flat_param.clone()
+    scaler.step(opt)
+    scaler.update()
+    torch.cuda.synchronize()
+    assert (rt.flat_param != before).float().mean().item() > 0.9 and torch.isfinite(rt.flat_param).all()

@@ -105,16 +105,12 @@ def test_sdxl_c64_tile_kernels_vs_generic_and_oracle(shape):
     small-width test above."""
     import os, subprocess, sys
     cfg, sd, batch, d_out, out, taps, grads = _run_wide(shape)
-    code = f"""
-import sys, torch
-sys.path[:0] = {sys.path!r}
+    from variant_utils import run_on_debug_build
+    ref = run_on_debug_build(f"""
 import test_sdxl_gpu as T
 cfg, sd, batch, d_out, out, taps, grads = T._run_wide({tuple(shape)!r})
-torch.save(dict(out=out, taps=taps, grads=grads), '/tmp/tcvn_sdxl_generic.pt')
-"""
-    env = dict(os.environ, TCVN_DISABLE_TILE="1", TCVN_HIP_LIBRARY="libtcvn_hip_dbg.so")
-    subprocess.check_call([sys.executable, "-c", code], env=env)
-    ref = torch.load("/tmp/tcvn_sdxl_generic.pt")
+result = dict(out=out, taps=taps, grads=grads)
+""", dict(TCVN_DISABLE_TILE="1"))
     e_taps = {k: ((taps[k] - ref["taps"][k]).norm() / ref["taps"][k].norm()).item() for k in taps}
     e_out = ((out - ref["out"]).norm() / ref["out"].norm()).item()
     e_grads = sorted(((((grads[k] - ref["grads"][k]).norm() / ref["grads"][k].norm().clamp_min(1e-30)).item(), k)
@@ -163,3 +159,56 @@ def test_sdxl_full_model_train_step_vs_oracle():
         _, _, ev_g, pr_g = model.shared_step(to_device(batch))
     _, _, ev_o, pr_o, _ = O.shared_step(sd, cfg, batch, training=False)
     assert rel_err(ev_g.cpu(), ev_o) < 1e-3 and rel_err(pr_g.cpu(), pr_o) < 1e-3
+
+
+@pytest.mark.parametrize("which", ["prong", "event"])
+def test_sdxl_production_width_at_400x280_vs_oracle(which):
+    """BASELINE config 4's own embedders on ONE 3x400x280 map each -- block widths [64,64,128,128,256,256,512,512,out], out = 256 (prong)
+    / 288 (event: not a multiple of 64, so its last stage runs the general kernels) -- bf16 forward + backward against the fp32 CPU
+    oracle (about 170 GFLOP of CPU work per map), inside the bf16 band of the small-width test.  Exercises every production tile
+    kernel at the production map sizes 400x280 ... 1x1 (k_sconv3_c64, k_sconv3_g, the stride-2 kernels, packing of the small maps,
+    the fused GroupNorm statistics).  Parity of this embedder stays unpinned (diffusers is not available)."""
+    from transformercvn.hip.engine import SdxlEngine
+    cfg = O.tutorial_config(embedder="sdxl", dropout=0.0, pixel_noise_std=0.0)          # tutorial widths: init 64, pixel embedding 256
+    pfx = f"network.prong_embedding.{which}_pixel_embedding"
+    pix, feat, pos = O.embed_dims(cfg)
+    out_dim = pix if which == "prong" else pix + feat
+    assert cfg.initial_pixel_dim == 64 and tuple(cfg.pixel_shape) == (400, 280) and out_dim == (256 if which == "prong" else 288)
+    sd = {k: v for k, v in O.fill_state(cfg, 17).items() if k.startswith(pfx + ".")}
+    batch = O.synthetic_batch([1], 8, cfg)
+    coords, values = (batch[5], batch[6]) if which == "prong" else (batch[2], batch[3])
+    d_out = torch.randn(1, out_dim, generator=torch.Generator().manual_seed(6))
+    # fp32 oracle
+    sdd = {k: v.float().requires_grad_(True) for k, v in sd.items()}
+    taps = {}
+    ref = S.sdxl_forward(sdd, pfx, O.preprocess_pixels(cfg, coords, values.float(), False), taps)
+    assert ref.shape == (1, out_dim) and tuple(taps[pfx + ":mid"].shape[2:]) == (1, 1)
+    gs = torch.autograd.grad(ref, list(sdd.values()), d_out, allow_unused=True)
+    g_ref = {k[len(pfx) + 1:]: (g if g is not None else torch.zeros_like(v)) for (k, v), g in zip(sdd.items(), gs)}
+    # HIP, bf16
+    eng = SdxlEngine(cfg.pixel_dim, out_dim, cfg.initial_pixel_dim, 2, 4, 400, 280, 1)
+    data = {k[len(pfx) + 1:]: v.cuda().contiguous() for k, v in sd.items()}
+    grads = {k: torch.zeros_like(v) for k, v in data.items()}
+    eng.bind(data, grads)
+    out = torch.empty(1, out_dim, device="cuda")
+    eng.forward(coords.cuda(), values.cuda(), 1, out, train=True, seed=1)
+    errs = {}
+    for tap in ("conv_in", "block0", "block1", "block2", "block4", "block8", "mid"):
+        mine = eng.tap(tap).permute(0, 3, 1, 2).float().cpu().double()
+        r = taps[f"{pfx}:{tap}"].detach().double()
+        errs[tap] = ((mine - r).norm() / r.norm()).item()
+    errs["out"] = ((out.cpu().double() - ref.detach().double()).norm() / ref.detach().double().norm()).item()
+    print(f"sdxl {which} embedder, production width at 400x280, bf16 vs fp32 oracle: forward rel L2", errs)
+    assert max(errs.values()) < 3e-2, errs
+    eng.backward(d_out.cuda())
+    torch.cuda.synchronize()
+    worst = []
+    for k, r in g_ref.items():
+        mine = grads[k].cpu().double().reshape(r.shape)
+        if "to_q" in k or "to_k" in k:
+            assert mine.abs().max().item() == 0.0
+            continue
+        worst.append((((mine - r.double()).norm() / r.double().norm().clamp_min(1e-30)).item(), k))
+    worst.sort(reverse=True)
+    print("worst gradient rel L2:", worst[:4])
+    assert worst[0][0] < 8e-2, worst[:6]

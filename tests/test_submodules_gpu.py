@@ -23,7 +23,7 @@ def _close(t, g, key, tol=5e-5):
     return err < tol
 
 
-@pytest.mark.parametrize("name", ["small_b3", "tutorial_b2p4", "tutorial_ragged"])
+@pytest.mark.parametrize("name", ["small_b3", "tutorial_b2p4", "tutorial_ragged", "tutorial_b2p8", "tutorial_b2p12"])
 @pytest.mark.parametrize("training", [False, True])
 def test_stage_by_stage_forward_matches_reference(name, training):
     cfg, over, batch, g = load_case(name)
@@ -82,13 +82,16 @@ def test_stage_calls_on_cpu_fail_loudly():
         model.network.event_decoder(torch.zeros(2, cfg.hidden_dim))
 
 
+@pytest.mark.parametrize("case", ["tutorial_ragged", "tutorial_b2p8", "tutorial_b2p12", "tutorial_b2p4"])
 @pytest.mark.parametrize("training", [False, True])
-def test_fused_encoder_matches_layer_by_layer_kernels(training):
+def test_fused_encoder_matches_layer_by_layer_kernels(training, case):
     """csrc/encoder_fused.hip (one launch, one workgroup per event) against the row kernels it replaces, same inputs, incl.
     dropout (same stateless masks) and a ragged key-padding mask: hidden states to fp32 summation-order level, and the saved
     tensors the backward reads (it runs on the unfused kernels either way) give the same parameter gradients."""
     from transformercvn.hip._lib import lib
-    cfg, over, batch, g = load_case("tutorial_ragged")               # prongs 1 / 16 / 5: S = 17 with padding
+    # ragged: prongs 1 / 16 / 5, S = 17 with padding (<16,11>); b2p8: S = 9 (<16,5>, BASELINE config 2); b2p12: S = 13 (<16,8>);
+    # b2p4: S = 5 (<16,3>, 2-layer encoder)
+    cfg, over, batch, g = load_case(case)
     sd = O.fill_state(cfg, int(g["weight_seed"]))
     res = {}
     for fused in (1, 0):
