@@ -143,8 +143,8 @@ def test_dropout_masks_and_noise_replayed_in_oracle_fp32(which):
     worst = 0.0
     for k, ref in grads.items():
         mine = named[k].grad.detach().cpu()
-        if is_noise_grad(k) or ref.abs().max() < 1e-6:
-            continue
+        if is_noise_grad(k) or ref.abs().max() < 1e-6 or k.endswith("event_position_embedding"):
+            continue            # (the position embedding feeds a train-mode BatchNorm1d only: exactly-zero true gradient, noise on both sides)
         l2 = ((mine - ref).norm() / ref.norm()).item()
         worst = max(worst, l2)
         assert l2 < 5e-3, (k, l2)           # a backward mask that differs from the forward mask gives O(1) errors
