@@ -127,7 +127,9 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
     L.c0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
     L.D.clear(); L.Y.clear(); L.bstatD.clear(); L.bstatY.clear(); L.YA.clear(); L.XA.clear(); L.XP.clear();
     L.zeros = b.take(1024);
+    L.sidx = sparse_stem_possible() ? b.take(stem_sparse_index_bytes(n, cfg.H, cfg.W)) : -1;
     long max_part = (long)pool0_grid(n, blocks[0].H, blocks[0].W) * cfg.init_ch * 16;
+    max_part = std::max(max_part, 1024L * cfg.init_ch * 16);      // sparse stem passes: <= 1024 workgroups
     max_part = std::max(max_part, 512L * cfg.init_ch * 16);
     long maxY = 0;
     for (const auto& bg : blocks) {
@@ -208,6 +210,9 @@ long DenseNetPlan::wk_bytes() const {
 bool DenseNetPlan::fast1_ok(int cin) const {
     const int mid = cfg.bn_size * cfg.growth;
     return cfg.mode == MODE_BF16 && conv3x3_tile_enabled() && mid % 8 == 0 && mid <= 256 && round_up(cin, 32) <= 640;
+}
+bool DenseNetPlan::sparse_stem_possible() const {
+    return cfg.mode == MODE_BF16 && cfg.in_ch >= 1 && cfg.in_ch <= 3 && cfg.init_ch == 64 && !blocks.empty() && (blocks[0].ld & 7) == 0;
 }
 bool tcvn::xa_materialize() {
     static const bool on = !TCVN_KNOB_SET("TCVN_XA_ONTHEFLY");   // default: write prelu(bn1(x)) to HBM once per layer.  A/B on
@@ -362,9 +367,38 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         return bn_link(a, st);
     };
 
-    // ---- pixel scatter + stem ----
-    TCVN_CHECK(hipMemsetAsync(ws + L.img, 0, (size_t)n * cfg.H * cfg.W * cfg.in_ch * esz, st));
+    // ---- stem ----
     TCVN_CHECK(hipMemsetAsync(ws + L.zeros, 0, 1024, st));
+    // Sparse-aware stem (bf16, 3 -> 64 channels, the hit list fits the index): conv0 + BN0 + PReLU0 + AvgPool straight from the COO
+    // list, neither the dense map nor the conv0 output is materialised (stem_sparse.hip).  Otherwise: scatter + dense kernels.
+    static const bool dense_stem_knob = TCVN_KNOB_SET("TCVN_DENSE_STEM");     // validation builds: force the dense stem kernels (A/B, parity tests)
+    const bool sparse_stem = !dense_stem_knob && L.sidx >= 0 &&
+                             stem_sparse_ok(mode, cfg.in_ch, cfg.init_ch, cfg.H, cfg.W, log_pixels, nnz, n, blocks[0].ld);
+    last_sparse_stem = sparse_stem;
+    last_values = values; last_value_mode = log_pixels; last_noise = train ? noise_std : 0.f;
+    int init_nblk = 0, init_ld = cfg.init_ch;
+    if (sparse_stem) {
+        const BlockGeom& b0 = blocks[0];
+        const WkEntry& e = wk_find(s_w0, 0);
+        StemSparseArgs sa{};
+        sa.coords = coords; sa.values = values; sa.nnz = nnz; sa.n_img = n; sa.H = cfg.H; sa.W = cfg.W; sa.Cpix = cfg.in_ch;
+        sa.value_mode = log_pixels; sa.noise_std = train ? noise_std : 0.f; sa.seed = seed;
+        sa.cells_y = cdiv(cfg.H, 32); sa.cells_x = cdiv(cfg.W, 32);
+        stem_sparse_carve(sa, ws + L.sidx);
+        sa.Wk = ws + L.wk + e.off; sa.Kp = e.Kp; sa.bias = data[s_b0];
+        sa.Hc = Hc; sa.Wc = Wc; sa.Ho = b0.H; sa.Wo = b0.W;
+        if ((rc = stem_sparse_index(sa, st))) return rc;
+        if (train) {
+            sa.part = part;
+            if ((rc = stem_sparse_stats(sa, st))) return rc;
+            if ((rc = link(n0, part, stem_sparse_stats_grid(sa), cfg.init_ch, 0, cfg.init_ch, reinterpret_cast<double*>(ws + L.bstat0), (long)n * Hc * Wc))) return rc;
+        }
+        Tab t = tab(n0);
+        sa.sc = t.sc; sa.sh = t.sh; sa.sl = data[s_a0]; sa.Out = ws + L.D[0]; sa.ldo = b0.ld; sa.part = train ? part : nullptr;
+        if ((rc = stem_sparse_pool(sa, st))) return rc;
+        init_nblk = stem_sparse_pool_grid(sa);
+    } else {
+    TCVN_CHECK(hipMemsetAsync(ws + L.img, 0, (size_t)n * cfg.H * cfg.W * cfg.in_ch * esz, st));
     {
         ScatterArgs a{mode, coords, values, nnz, n, ws + L.img, cfg.H, cfg.W, cfg.in_ch, log_pixels, train ? noise_std : 0.f, seed};
         if ((rc = scatter_pixels(a, st))) return rc;
@@ -387,8 +421,9 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                     train ? part : nullptr, pool0_grid(n, b0.H, b0.W)};
         if ((rc = pool0_fwd(a, st))) return rc;
     }
-    // statistics of the block's initial channels are described by (prev_part_nblk, prev_part_ld)
-    int init_nblk = pool0_grid(n, blocks[0].H, blocks[0].W), init_ld = cfg.init_ch;
+    init_nblk = pool0_grid(n, blocks[0].H, blocks[0].W);
+    }
+    // statistics of the block's initial channels are described by (init_nblk, init_ld)
 
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
         const BlockGeom& bg = blocks[bi];
@@ -505,6 +540,7 @@ int DenseNetPlan::tap(int n, const char* name, long* off, int* tn, int* th, int*
     layout(n, false, L);
     std::string s(name);
     *tn = n; *tes = esz;
+    if ((s == "img" || s == "conv0") && last_sparse_stem && n == last_n) return -1;      // the sparse stem materialises neither
     if (s == "img") { *off = L.img; *th = cfg.H; *tw = cfg.W; *tc = cfg.in_ch; *tld = cfg.in_ch; return 0; }
     if (s == "conv0") { *off = L.c0; *th = Hc; *tw = Wc; *tc = cfg.init_ch; *tld = cfg.init_ch; return 0; }
     if (s == "condense") { *off = L.F; *th = 1; *tw = 1; *tc = Cf; *tld = Cf; *tes = 4; return 0; }

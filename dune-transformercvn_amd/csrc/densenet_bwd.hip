@@ -34,6 +34,7 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     L.G.clear(); L.pqD.clear();
     // --- zeroed at the start of every backward: G, pqD, gwk (contiguous) ---
     long bpart = (long)std::max(pool0_bwd_grid(n, Hc, Wc), pool0_bwd_vec_grid(n, Hc, Wc)) * cfg.init_ch * 24;
+    bpart = std::max(bpart, 1024L * cfg.init_ch * 24);              // sparse stem backward: <= 1024 workgroups
     bpart = std::max(bpart, (long)head_pool_bwd_grid(n) * Cf * 24);
     for (const auto& bg : blocks) {
         const long M = (long)n * bg.H * bg.W;
@@ -335,6 +336,23 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
         float* Q0 = P0 + cfg.init_ch;
         const long M0 = (long)n * Hc * Wc;
         EffSrc e{ws + L.G[0], b0.ld, ws + L.D[0], b0.ld, 0, cfg.init_ch, P, Q, 0.f, 0, 0};
+        if (last_sparse_stem) {
+            // stem_sparse.hip: pass 0 = pooling / PReLU0 / BN0 backward sums with the conv0 output rebuilt from the hit list per region;
+            // pass 1 = conv0 weight gradient from the same regions with (P0, Q0) applied.  No conv0-sized tensor is read or written.
+            const WkEntry& ef = wk_find(s_w0, 0);
+            StemSparseArgs sa{};
+            sa.coords = last_coords; sa.values = last_values; sa.nnz = last_nnz; sa.n_img = n; sa.H = cfg.H; sa.W = cfg.W; sa.Cpix = cfg.in_ch;
+            sa.value_mode = last_value_mode; sa.noise_std = last_noise; sa.seed = seed;
+            sa.cells_y = cdiv(cfg.H, 32); sa.cells_x = cdiv(cfg.W, 32);
+            stem_sparse_carve(sa, ws + L.sidx);
+            sa.Wk = ws + L.wk + ef.off; sa.Kp = ef.Kp; sa.bias = data[s_b0];
+            sa.Hc = Hc; sa.Wc = Wc; sa.Ho = b0.H; sa.Wo = b0.W;
+            sa.sc = sc_of(n0); sa.sh = sh_of(n0); sa.sl = data[s_a0]; sa.e = e; sa.part = part;
+            if ((rc = stem_sparse_bwd(sa, 0, st))) return rc;
+            if ((rc = bwd_link(n0, stem_sparse_bwd_grid(sa), reinterpret_cast<const double*>(ws + L.bstat0), M0, P0, Q0, 0, s_a0))) return rc;
+            sa.P0 = P0; sa.Q0 = Q0; sa.slab = reinterpret_cast<float*>(ws + L.slab); sa.slab_bytes = kSlabBytes; sa.dWk = gw_of(s_w0);
+            if ((rc = stem_sparse_bwd(sa, 1, st))) return rc;
+        } else {
         Pool0BwdArgs a{mode, ws + L.c0, n, Hc, Wc, cfg.init_ch, sc_of(n0), sh_of(n0), data[s_a0], e, b0.H, b0.W, ws + L.du0, part,
                        pool0_bwd_grid(n, Hc, Wc)};
         const bool vec = pool0_bwd_vec_ok(a) && conv3x3_tile_enabled();
@@ -354,6 +372,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                              reinterpret_cast<float*>(ws + L.slab), kSlabBytes, mode};
             if ((rc = stem_wgrad_sparse(sa, gw_of(s_w0), st))) return rc;
         } else if ((rc = conv_wgrad(w, st))) return rc;
+        }
     }
     // kernel-layout weight gradients of the blocks just finished -> reference OIHW gradients (conv0 rides with block 0)
     const int u0 = last_part ? 0 : unpack_first[bi_lo], u1 = unpack_first[bi_hi + 1];

@@ -24,6 +24,7 @@ struct Layout {
     std::vector<long> D, bstatD;
     std::vector<std::vector<long>> Y, bstatY, YA;     // YA: activated bf16 copies of Y (bf16 mode)
     long zeros, ey, ey2, slab;
+    long sidx;                           // sparse-stem bucket index (stem_sparse.hip), -1 when the plan cannot use it
     std::vector<std::vector<long>> XA;   // activated bf16 copies of the 1x1-conv inputs (per layer, -1 if absent)
     std::vector<long> XP;                // pooled activated transition inputs (-1 if absent)
     // backward
@@ -53,6 +54,9 @@ struct DenseNetPlan {
     char* desc_ws = nullptr; long desc_total = 0; int n_pack = 0, n_bneval = 0;
     uint64_t last_seed = 0; int last_n = 0;
     const int32_t* last_coords = nullptr; long last_nnz = 0;     // COO list of the last forward (sparse stem weight gradient)
+    const float* last_values = nullptr; int last_value_mode = 0; float last_noise = 0.f;
+    bool last_sparse_stem = false;       // the last forward ran the sparse-aware stem: no dense map / conv0 output exists (backward must match)
+    bool sparse_stem_possible() const;   // plan-level condition (bf16, 3 -> 64 channels); the hit count decides per call
     // weight-gradient side stream of backward (3x3 and 1x1 weight gradients run beside the data-gradient chain)
     hipStream_t side_st = nullptr; hipEvent_t ev_fork_a = nullptr, ev_fork_b = nullptr, ev_done[2] = {nullptr, nullptr}, ev_drain = nullptr;
     int ensure_side();

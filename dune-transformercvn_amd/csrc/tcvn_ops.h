@@ -249,6 +249,34 @@ bool stem_fwd_ok(const ConvFwdArgs& a);
 int stem_fwd_nblk(const ConvFwdArgs& a);
 int stem_fwd_bf16(const ConvFwdArgs& a, hipStream_t st);
 
+// Sparse-aware stem (stem_sparse.hip, bf16 mode): conv0 + BatchNorm0 + PReLU0 + AvgPool(3,2) and their backward from the COO hit
+// list; neither the dense pixel map nor the conv0 output exists in HBM.  One argument block serves the index build and all passes.
+struct StemSparseArgs {
+    const int* coords; const float* values; long nnz;       // COO list [nnz][3] (image, y, x), values [nnz][Cpix]
+    int n_img, H, W, Cpix, value_mode; float noise_std; uint64_t seed;
+    int cells_y, cells_x;                                    // 32 x 32-pixel bucket cells per map
+    int *cell_start, *cell_fill, *cell_hits; float4* pv;     // index (stem_sparse_carve): prefix, cursors, bucketed hit ids, preprocessed values
+    const void* Wk; int Kp; const float* bias;               // conv0 weights [64][Kp] bf16 (k = tap*Cpix + c), bias fp32
+    int Hc, Wc, Ho, Wo;                                      // conv0 output map, pooled map
+    const float *sc, *sh, *sl;                               // BatchNorm0 (scale, shift) table, PReLU0 slope
+    void* Out; long ldo;                                     // pooled map -> first 64 channels of dense block 1 (bf16)
+    double* part;                                            // per-workgroup statistics partials ([grid][64][2] forward, [grid][64][3] backward)
+    EffSrc e;                                                // backward: gradient of the pooled map (G, x = the pooled map, P, Q)
+    const float *P0, *Q0;                                    // backward pass 1: BatchNorm0's (P, Q)
+    float* slab; long slab_bytes; float* dWk;                // backward pass 1: per-workgroup partial weight gradients, result [64][Kp]
+};
+long stem_sparse_hit_capacity(int n_img);
+long stem_sparse_index_bytes(int n_img, int H, int W);
+void stem_sparse_carve(StemSparseArgs& a, char* base);      // points the index arrays into a buffer of stem_sparse_index_bytes()
+bool stem_sparse_ok(int mode, int in_ch, int init_ch, int H, int W, int value_mode, long nnz, int n_img, long ldo);
+int stem_sparse_stats_grid(const StemSparseArgs& a);
+int stem_sparse_pool_grid(const StemSparseArgs& a);
+int stem_sparse_bwd_grid(const StemSparseArgs& a);
+int stem_sparse_index(const StemSparseArgs& a, hipStream_t st);
+int stem_sparse_stats(const StemSparseArgs& a, hipStream_t st);
+int stem_sparse_pool(const StemSparseArgs& a, hipStream_t st);
+int stem_sparse_bwd(const StemSparseArgs& a, int pass, hipStream_t st);      // pass 0: backward sums; pass 1: conv0 weight gradient
+
 // kernel-layout fp32 weight gradients -> reference OIHW gradients (accumulate)
 struct UnpackDesc { const float* src; float* dst; int N, Cin, taps, Kp; int nfast; };   // nfast: src is [k][32]
 int unpack_wgrads(const UnpackDesc* d_descs, int n, hipStream_t st);

@@ -253,6 +253,8 @@ def main():
     run_case("tutorial_b2p8", dict(), [8, 8], batch_seed=14, weight_seed=4)
     # 12 prongs/event (S = 13: the <16,8> instantiation; the middle of config 5's ragged range)
     run_case("tutorial_b2p12", dict(), [12, 12], batch_seed=15, weight_seed=5)
+    # BASELINE config 2 itself: 32 DISTINCT events x 8 prongs (288 maps), full model -- minutes of reference CPU time, ~3 MB fixture
+    run_case("tutorial_b32p8", dict(), [8] * 32, batch_seed=16, weight_seed=6)
     # reduced network for fast layer-by-layer debugging
     run_case("small_b3", dict(densenet_structure=[2, 2], densenet_growth_rate=8, initial_pixel_dim=16,
                               num_encoder_layers=2, pixel_embedding_dim=64, hidden_dim=64,

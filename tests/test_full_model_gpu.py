@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 LOGIT_GATE = 1e-3          # BASELINE.json north_star
 # b2p8 / b2p12: hidden 128, 6-layer encoder, S = 9 / 13 -> the <16,5> and <16,8> row buckets of csrc/encoder_fused.hip (the ones
 # BASELINE config 2 and the middle of config 5's ragged range run); ragged: S = 17 -> <16,11>; b2p4: S = 5 -> <16,3>
-CASES = ["small_b3", "tutorial_b2p4", "tutorial_ragged", "tutorial_b2p8", "tutorial_b2p12"]
+CASES = ["small_b3", "tutorial_b2p4", "tutorial_ragged", "tutorial_b2p8", "tutorial_b2p12"]      # (tutorial_b32p8: tests/test_fullsize_gpu.py)
 
 
 def _loaded_so():
@@ -88,18 +88,27 @@ def test_train_step_matches_reference(name):
     assert rel_err(pr.cpu(), g["train_prong_logits"]) < LOGIT_GATE
 
 
-# Measured on MI355X: eval 1.3e-3 (small net) ... 1.3e-2 (tutorial net, event logits); the reference's
-# own bf16 autocast sits at 2.6-3.5e-3 in eval mode.  Train mode on the golden batches is degenerate for bf16: they
-# hold 2-3 events, and BatchNorm1d over 2-3 rows maps the event embeddings to about -1/+1 whatever their size, so bf16 rounding
-# of the embeddings moves the logits by up to 0.16 there -- reported, loosely gated; the 64-event train step of
-# test_fullsize_gpu.py is the meaningful train-mode bf16 check (loss within 3e-2 of the golden).
-BF16_EVAL_GATE, BF16_TRAIN_GATE = 2e-2, 2.5e-1
+# The bf16 throughput mode is gated against the REFERENCE'S OWN bf16 behaviour on the same inputs and weights:
+# tests/golden/autocast_bf16_band.npz (oracle/make_autocast_band.py) holds the logits of the real reference module run under
+# torch.autocast(bfloat16) -- what `train.py -fp16` selects up to the half type -- on every golden case.  Its max-norm relative
+# logit error against the fp32 goldens is 0.9-2.7e-2 in eval mode and 0.02-0.74 in train mode (train mode on these batches is
+# degenerate for any 16-bit format: they hold 2-3 events, and BatchNorm1d over 2-3 rows maps the event embeddings to about -1/+1
+# whatever their size, so roundings of the embeddings move the logits a lot).  Measured here on MI355X: eval 1.3e-3 (small net) ...
+# 1.3e-2 (tutorial nets), train 0.02-0.34 -- inside the reference's band on every case.  Gates: eval <= 1.25 x the band and <= 2e-2
+# absolute; train <= 1.25 x the band.  The 32-event train step of test_fullsize_gpu.py is the meaningful train-mode bf16 check.
+BF16_EVAL_GATE, BAND_SLACK = 2e-2, 1.25
+
+
+def autocast_band(name):
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "autocast_bf16_band.npz"))
+    return d, d[f"{name}:logit_err"]
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_bf16_full_model_logit_error_vs_reference(name):
     """The throughput mode end to end (precision="bf16": bf16 DenseNets, fp32 token path) against the reference's fp32 golden
-    logits: prints and gates the max-norm relative logit error in eval and train mode (dropout = noise = 0)."""
+    logits, next to the error of the reference's own bf16 autocast run on the same case (dropout = noise = 0)."""
     cfg, over, batch, g = load_case(name)
     sd = O.fill_state(cfg, int(g["weight_seed"]))
     model = build_trainer(cfg, sd, precision="bf16")
@@ -114,8 +123,11 @@ def test_bf16_full_model_logit_error_vs_reference(name):
     with torch.no_grad():
         _, _, ev, pr = model.shared_step(dbatch)
     t_ev, t_pr = rel_err(ev.cpu(), g["train_event_logits"]), rel_err(pr.cpu(), g["train_prong_logits"])
-    print(f"BF16 LOGIT ERROR {name}: eval event {e_ev:.3e} prong {e_pr:.3e}; train event {t_ev:.3e} prong {t_pr:.3e}")
-    assert max(e_ev, e_pr) < BF16_EVAL_GATE and max(t_ev, t_pr) < BF16_TRAIN_GATE
+    _, band = autocast_band(name)
+    print(f"BF16 LOGIT ERROR {name}: eval event {e_ev:.3e} prong {e_pr:.3e}; train event {t_ev:.3e} prong {t_pr:.3e}   "
+          f"[reference under bf16 autocast: eval {band[0]:.3e} {band[1]:.3e}; train {band[2]:.3e} {band[3]:.3e}]")
+    assert max(e_ev, e_pr) < BF16_EVAL_GATE and max(e_ev, e_pr) <= BAND_SLACK * max(band[0], band[1])
+    assert max(t_ev, t_pr) <= BAND_SLACK * max(band[2], band[3])
 
 
 def test_cpu_tensors_fail_loudly():

@@ -1,11 +1,9 @@
-"""BASELINE config 2 at its own shape -- 32 events x 8 prongs/event (256 prong maps + 32 event maps, S = 9 tokens per event) in one
-step -- against the reference's golden vectors.
-
-A batch made of k copies of a golden batch has, per copy, the golden's eval logits (events are independent in eval mode) and
--- because duplicating every sample leaves each BatchNorm's batch mean / biased variance unchanged -- also the golden's
-train-mode logits, losses and parameter gradients (the loss is a mean over k times as many identical rows).  Unbiased
-running variances differ by n/(n-1) and are not compared.  That pins the full-size forward AND backward launches (grids of
-256-512 workgroups, 13.7 k tiles per 3x3 launch) to reference numbers without a CPU run at that size."""
+"""BASELINE config 2 at its own shape against a golden made by the REFERENCE at that shape: 32 distinct events x 8 prongs/event (256
+prong maps + 32 event maps, S = 9 tokens per event), hidden 128, 6-layer encoder -- tests/golden/tutorial_b32p8.npz, written by
+oracle/make_golden.py from the real reference module (3.4 minutes of CPU time).  One step here is exactly the step bench.py times
+(minus dropout / noise, which tests/test_dropout_noise_gpu.py replays): eval logits, train loss and logits, the 26 sentinel gradients
+and all 782 gradient norms are compared with the reference's own numbers.  With 32 distinct events no BatchNorm1d is degenerate, so
+the bf16 mode's train-mode numbers are meaningful here (they are not on the 2-3 event goldens)."""
 import numpy as np
 import pytest
 import torch
@@ -31,8 +29,8 @@ def tile_batch(batch, k):
             pv.repeat(k, 1), pm.repeat(k, 1), et.repeat(k), pt.repeat(k, 1))
 
 
-CASE = "tutorial_b2p8"      # 2 events x 8 prongs, hidden 128, 6-layer encoder (made from the reference by oracle/make_golden.py)
-K = 16                      # 16 copies -> exactly BASELINE config 2: 32 events, 256 prong maps, 8 prongs/event
+CASE = "tutorial_b32p8"     # 32 distinct events x 8 prongs: BASELINE config 2 itself (made from the reference by oracle/make_golden.py)
+K = 1                       # (tile_batch(batch, k) can still replicate a golden batch k times; the real case needs no copies)
 
 
 @pytest.mark.parametrize("precision,gate", [("fp32", 1e-3), ("bf16", 2e-2)])
@@ -51,7 +49,11 @@ def test_config2_sized_eval_logits_equal_golden_per_copy(precision, gate):
         worst = max(worst, rel_err(ev[c * B:(c + 1) * B], g["eval_event_logits"]), rel_err(pr[c * B:(c + 1) * B], g["eval_prong_logits"]))
     print(f"{precision}: 32 events x 8 prongs (256 prong maps), worst per-copy eval logit error vs reference golden {worst:.3e}")
     assert worst < gate
-    assert rel_err(ev[:B], ev[-B:]) < (1e-6 if precision == "fp32" else 1e-2)      # copies agree with each other
+    if precision == "bf16":
+        import os
+        bl = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "autocast_bf16_band.npz"))[f"{CASE}:logit_err"]
+        print(f"   reference under bf16 autocast on the same step: eval event {bl[0]:.3e} prong {bl[1]:.3e}")
+        assert worst <= 1.25 * max(bl[0], bl[1])
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -73,16 +75,20 @@ def test_config2_sized_train_step_equals_golden(precision):
     assert abs(loss.item() - ref) < (1e-4 if fp32 else 3e-2) * abs(ref)
     named = dict(model.named_parameters())
     worst = 0.0
+    import os
+    band = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "autocast_bf16_band.npz"))
     for k in [k for k in g if k.startswith("grad:")]:
         mine, r = named[k[5:]].grad.cpu().numpy(), g[k]
         if fp32:
             assert grad_close(k[5:], mine, r, rtol=5e-2), k
-        elif np.abs(r).max() > 1e-6 and "bias" not in k and "event_pixel_embedding" not in k:
-            # (the golden batch holds TWO distinct event maps: BatchNorm1d over two values maps them to -1 / +1 whatever their
-            #  size, so the event embedder's true gradient is a cancellation residue of order eps: noise in bf16)
+        elif np.abs(r).max() > 1e-6 and not is_noise_grad(k[5:]) and not k.endswith("event_position_embedding"):
             cos = float((mine.ravel() * r.ravel()).sum() / (np.linalg.norm(mine) * np.linalg.norm(r) + 1e-30))
             worst = max(worst, 1 - cos)
-            assert cos > 0.9, (k, cos)
+            # next to it: the cosine the reference's own bf16 autocast backward reaches with its fp32 gradients on this very step
+            # (tests/golden/autocast_bf16_band.npz); gate = that band with 0.1 of slack, capped at 0.9
+            ref_cos = float(band[f"{CASE}:gradcos:{k[5:]}"])
+            print(f"   bf16 gradient cosine {k[5:][-56:]:56s} here {cos:.3f}   reference under autocast {ref_cos:.3f}")
+            assert cos > min(0.9, ref_cos - 0.1), (k, cos, ref_cos)
     # all 782 gradient norms of the reference step
     if fp32:
         for k, n_ref in zip(g["grad_keys"], g["grad_norms"]):
@@ -94,6 +100,9 @@ def test_config2_sized_train_step_equals_golden(precision):
     B = batch[0].shape[0]
     e = max(rel_err(ev[:B].cpu(), g["train_event_logits"]), rel_err(pr[-B:].cpu(), g["train_prong_logits"]))
     print(f"{precision}: full-size train-mode logit error vs golden {e:.3e}; worst 1-cos of sentinel grads {worst:.3e}")
-    # bf16: the batch has 2 distinct events, so BatchNorm1d of the event rows is the degenerate -1/+1 case (see
-    # test_full_model_gpu.py) -- the loss above is the bf16 gate, the logits are reported only
-    assert e < 1e-3 or not fp32
+    if fp32:
+        assert e < 1e-3
+    else:       # 32 distinct events: train-mode logits are meaningful in bf16 here -- gate against the reference's own autocast band
+        bl = band[f"{CASE}:logit_err"]
+        print(f"bf16 train-mode logit error {e:.3e}; reference under bf16 autocast: event {bl[2]:.3e} prong {bl[3]:.3e}")
+        assert e <= 1.25 * max(bl[2], bl[3])

@@ -87,6 +87,7 @@ def test_amp_grad_scaler_flow_on_the_arena_views():
     fused optimizer."""
     from model_utils import build_trainer, to_device
     from golden_utils import load_case, train_cfg
+    from oracle import tcvn_oracle as O
     cfg, over, batch, g = load_case("small_b3")
     cfg = train_cfg(over)
     sd = O.fill_state(cfg, int(g["weight_seed"]))

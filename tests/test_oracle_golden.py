@@ -21,7 +21,7 @@ def grad_close(key, mine, ref, rtol=6e-3):
     return rel_err(mine, ref) < rtol
 
 
-CASES = ["small_b3", "tutorial_b2p4", "tutorial_ragged", "tutorial_b2p8", "tutorial_b2p12"]
+CASES = ["small_b3", "tutorial_b2p4", "tutorial_ragged", "tutorial_b2p8", "tutorial_b2p12", "tutorial_b32p8"]
 
 
 def test_state_layout_matches_reference_counts():
