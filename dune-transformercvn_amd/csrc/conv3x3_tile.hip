@@ -6,6 +6,7 @@
 // read it with row offsets (ds_read_b128, XOR-swizzled, conflict free); weights stream from L2 in fragment order.
 // Algorithmic work per launch: 2 * pixels * 32 * 1152 FLOP; HBM: read 128 ch + write 32 ch per pixel.
 #include <cstdlib>
+#include <type_traits>
 #include "tile3x3.h"
 #include "prof.h"
 
@@ -301,6 +302,188 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_ring_bf16(const ConvFwdA
     }
 }
 size_t fwd_ring_smem() { return RING * 256 + RING * 4 + 4 * 32 * 16; }
+
+// Pair variant of the ring kernel: 512 threads = two waves per SIMD.  The ablation of the ring kernel (tools/ablate_conv3x3.py: block 1,
+// 277 us = 76 fixed + 47 DMA issue + 86 MFMA + 68 epilogue, nothing overlapping) says a single wave per SIMD serialises its phases; here the
+// two waves of a SIMD split the NINE TAPS of the same 32 positions -- wave w (role A) owns taps 0-4 (40 weight fragments = 160 registers),
+// wave w+4 (role B) taps 5-8 (32 fragments) -- which is what fits the 256 registers a wave has at two waves per SIMD, and they run
+// skewed by half a tile: after the tile barrier, B first finishes tile t-1 (adds A's partial sums, exchanged through LDS, applies bias /
+// dropout, stores, statistics) while A already multiplies tile t; then B multiplies its taps of tile t.  A also fills the pixel table.
+// The matrix pipe of the SIMD sees the same 72 MFMAs per tile, but the epilogue, the table arithmetic, the LDS waits and the DMA issue of
+// one wave now sit under the other wave's MFMAs.  Ring rows are sized from the map width (rows() + 128, multiple of 16) so that the LDS
+// also holds the two exchange buffers: 100 KB + 32 KB at W = 69.
+constexpr int PAIR_TBL = 1024;       // table entries (power of two > 512 + halo: an entry lives two tiles longer than its image row)
+__global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdArgs g, int n_img, int ntiles, int ring) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PadGeom q(n_img, g.H, g.W);
+    const int nrows4 = (q.rows() + 3) & ~3;
+    int* tbl = reinterpret_cast<int*>(smem + ring * 256);                             // [1024] pixel index of row (row-space index & 1023): an entry
+                                                                                      // outlives its image row (the deferred epilogue reads it a tile later)
+    float* xchg = reinterpret_cast<float*>(smem + ring * 256 + PAIR_TBL * 4);         // [2][4 pairs][16][64] role A's partial sums
+    double* red = reinterpret_cast<double*>(xchg + 2 * 4 * 16 * 64);                  // [4][32][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool roleB = wave >= 4;
+    const int pw = wave & 3;                                                          // pair index = 32-position block of the tile
+    const int r = lane & 31, h = lane >> 5;
+    const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
+    const bf16* __restrict__ YA = reinterpret_cast<const bf16*>(g.Aact);
+    const char* __restrict__ zeros = reinterpret_cast<const char*>(g.zeros);
+    bf16* __restrict__ Out = reinterpret_cast<bf16*>(g.Out);
+    const int nb = gridDim.x, base = ntiles / nb, rem = ntiles % nb;
+    const int t0 = blockIdx.x * base + min((int)blockIdx.x, rem), t1 = t0 + base + ((int)blockIdx.x < rem ? 1 : 0);
+    const int g_org = t0 * TP - q.halo;
+    const bool nok = r < g.N;
+    const float bias = nok ? g.bias[r] : 0.f;
+    const bool drop = g.drop_p > 0.f;
+    const uint32_t dkey = drop_key(g.seed, g.stream_id);
+    auto wrap = [&](int x) { return x >= ring ? x - ring : x; };                      // x in [0, 2 * ring)
+
+    // weight fragment (tap, ks) sits at ((tap*8 + ks)*64 + lane)*8; role A keeps taps 0..4 in registers, role B taps 5..8
+    const bf16* __restrict__ Wf = reinterpret_cast<const bf16*>(g.Wfrag) + lane * 8;
+
+    // rows [row0, row0 + n) of this workgroup's row space (row 0 = g_org); image row -> ring slot (row mod ring), table entry row & 1023
+    auto fill_rows = [&](int row0, int n, int t, int nt) {                            // by threads [t, t + nt)
+        for (int i = t; i < n; i += nt) tbl[(row0 + i) & (PAIR_TBL - 1)] = pix_of(q, g_org + row0 + i, invWp, invHp);
+    };
+    auto dma_rows = [&](int row0, int slot0, int n) {                                 // n multiple of 4; 4 rows (1 KiB) per wave instruction, 8 waves
+        const int rsub = lane >> 4, slot = lane & 15;
+        for (int rg = wave; rg * 4 < n; rg += 8) {
+            const int ring_row = wrap(slot0 + rg * 4);                                // slot0, ring multiples of 4: a group never wraps
+            const int rr = ring_row + rsub;
+            const int m = tbl[(row0 + rg * 4 + rsub) & (PAIR_TBL - 1)];
+            const char* src = m >= 0 ? reinterpret_cast<const char*>(YA + (long)m * 128) + ((slot ^ (rr & 15)) << 4) : zeros + (slot << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + ring_row * 256), 16, 0, 0);
+        }
+    };
+    if (t0 < t1) fill_rows(0, nrows4, tid, 512);
+    if (t0 + 1 < t1) fill_rows(nrows4, TP, tid, 512);
+    __syncthreads();
+    if (t0 < t1) dma_rows(0, 0, nrows4);
+
+    double s1 = 0, s2 = 0;
+    f32x16 accp;                                                                      // role B: its partial sums of the previous tile
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accp[e] = 0.f;
+    int slot_tile = 0;                                                                // ring slot of the current tile's first image row
+    int slot_new = wrap(nrows4);                                                      // ring slot of the NEXT tile's first new row
+    // role B's deferred epilogue of tile `te` (its first image row sat in ring slot `slot_e`): partial sums of both waves, bias, dropout,
+    // store, statistics
+    auto epilogue = [&](int te, const f32x16& mine) {
+        const float* xc = xchg + (((te - t0) & 1) * 4 + pw) * 16 * 64 + lane;
+        float part[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[e] = xc[e * 64];
+        int mrow[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mrow[e] = tbl[((te - t0) * TP + q.halo + pw * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) & (PAIR_TBL - 1)];
+        long cur_grp = -1;
+        uint32_t bits = 0;
+        float f1 = 0.f, f2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = mrow[e];
+            if (m >= 0 && nok) {
+                float v = mine[e] + part[e] + bias;
+                if (drop) {
+                    if ((m >> 1) != cur_grp) { cur_grp = m >> 1; bits = drop_bits(dkey, m, r, g.N); }
+                    v *= drop_pick(bits, m, g.drop_p);
+                }
+                const bf16 o = f2bf(v);
+                Out[(long)m * g.ldo + g.n_off + r] = o;
+                const float x = bf2f(o);
+                f1 += x; f2 = fmaf(x, x, f2);
+            }
+        }
+        s1 += (double)f1; s2 += (double)f2;
+    };
+
+    // one multiply pass: NT taps starting at tap `tap_first` over the 32 positions of this pair, image of the tile in ring slot `slot_t`.
+    // The A fragments travel LDS -> registers four k-steps (half a tap) ahead of the MFMAs that consume them: two register groups of
+    // four fragments; without the prefetch every MFMA waits for its own ds_read (measured: 243 us instead of 277 for block 1 only).
+    auto multiply = [&](auto& bwr, auto ntc, int tap_first, int slot_t, f32x16& acc) {
+        constexpr int NT = decltype(ntc)::value, NG = NT * 2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const int lrow0 = slot_t + pw * 32 + r + q.halo;                               // < 2 * ring; tap shifts add at most Wp + 1 < ring more
+        auto row_of = [&](int tp) {
+            const int tap = tap_first + tp;
+            int lr = lrow0 + (tap / 3 - 1) * q.Wp + (tap % 3 - 1);
+            lr = lr >= ring ? lr - ring : lr;
+            return lr >= ring ? lr - ring : lr;
+        };
+        bf16x8_t af[2][4];
+        auto load_group = [&](int gI, bf16x8_t (&dst)[4]) {
+            const int lr = row_of(gI >> 1), ks0 = (gI & 1) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dst[i] = *reinterpret_cast<const bf16x8_t*>(smem + lr * 256 + (((2 * (ks0 + i) + h) ^ (lr & 15)) << 4));
+        };
+        load_group(0, af[0]);
+#pragma unroll
+        for (int gI = 0; gI < NG; ++gI) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0) BEFORE the next group's reads are issued: this group's fragments (read four
+            __builtin_amdgcn_sched_barrier(0);          // MFMAs ago) are in; placed by hand because hipcc would put the wait behind the new reads
+            if (gI + 1 < NG) load_group(gI + 1, af[(gI + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);          // keep the four reads ahead of the four MFMAs (hipcc otherwise sinks them next to their uses)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[gI & 1][i], bwr[gI * 4 + i], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // The two roles run the same barrier sequence (one __syncthreads per tile + one after the loop) on their own register sets.
+    if (!roleB) {
+        bf16x8_t bw[40];
+#pragma unroll
+        for (int i = 0; i < 40; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + i * 512);
+        for (int t = t0; t < t1; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's share of tile t's rows has landed
+            __syncthreads();                                                          // ... everybody's; tile t-1's MFMAs are done; xchg / tbl of the last phase visible
+            if (t + 1 < t1) dma_rows(nrows4 + (t - t0) * TP, slot_new, TP);            // the next tile's 128 new rows travel under this tile's work
+            f32x16 acc;
+            multiply(bw, std::integral_constant<int, 5>{}, 0, slot_tile, acc);
+            float* xc = xchg + (((t - t0) & 1) * 4 + pw) * 16 * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xc[e * 64] = acc[e];
+            // table of the rows the NEXT iteration will fetch (tile t + 2's new rows), by the 256 role-A threads
+            if (t + 2 < t1) fill_rows(nrows4 + (t - t0 + 1) * TP, TP, tid, 256);
+            slot_tile = wrap(slot_tile + TP);
+            slot_new = wrap(slot_new + TP);
+        }
+    } else {
+        bf16x8_t bw[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + (40 + i) * 512);
+        for (int t = t0; t < t1; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // DMA share landed, stores of the last epilogue left
+            __syncthreads();
+            if (t + 1 < t1) dma_rows(nrows4 + (t - t0) * TP, slot_new, TP);
+            if (t > t0) epilogue(t - 1, accp);                                         // finish tile t-1 while role A multiplies tile t
+            multiply(bw, std::integral_constant<int, 4>{}, 5, slot_tile, accp);
+            slot_tile = wrap(slot_tile + TP);
+            slot_new = wrap(slot_new + TP);
+        }
+    }
+    __syncthreads();                                                                  // the last tile's exchange buffer is complete
+    if (roleB && t1 > t0) epilogue(t1 - 1, accp);
+    if (g.part != nullptr) {
+        double a = s1, b = s2;
+        a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+        if (roleB && lane < 32) { red[(pw * 32 + lane) * 2] = a; red[(pw * 32 + lane) * 2 + 1] = b; }
+        __syncthreads();
+        if (tid < g.N) {
+            double x = 0, y = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { x += red[(w * 32 + tid) * 2]; y += red[(w * 32 + tid) * 2 + 1]; }
+            g.part[((long)blockIdx.x * g.N + tid) * 2] = x;
+            g.part[((long)blockIdx.x * g.N + tid) * 2 + 1] = y;
+        }
+    }
+}
+int fwd_pair_ring(const PadGeom& q) { return (int)((((q.rows() + 3) & ~3) + TP + 15) & ~15); }
+size_t fwd_pair_smem(const PadGeom& q) { const size_t ring = fwd_pair_ring(q); return ring * 256 + PAIR_TBL * 4 + 2 * 4 * 16 * 64 * 4 + 4 * 32 * 16; }
+
 
 size_t fwd_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return 2 * r4 * 256 + 3 * r4 * 4 + 4 * 32 * 16; }
 
@@ -849,6 +1032,17 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
     ConvFwdArgs b = a;
     static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
     b.dbg = dbg;
+    if (fwd_pair_smem(q) <= 160 * 1024 && 4 * TP + q.halo + q.Wp + 1 < PAIR_TBL && !TCVN_DBG_BIT(dbg, 32) && !TCVN_DBG_BIT(dbg, 64)) {   // two waves per SIMD, taps split (TCVN_DBG=64: one-wave ring kernel)
+        static bool attr3 = false;
+        if (!attr3) {
+            TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_fwd_pair_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
+            attr3 = true;
+        }
+        hipLaunchKernelGGL(k_conv3x3_fwd_pair_bf16, dim3(nb), dim3(512), fwd_pair_smem(q), st, b, n_img, ntiles, fwd_pair_ring(q));
+        TCVN_LAUNCH_CHECK();
+        return 0;
+    }
     if (((q.rows() + 3) & ~3) + TP <= RING && !TCVN_DBG_BIT(dbg, 32)) {       // consecutive tiles per workgroup, ring image (TCVN_DBG=32: strips)
         static bool attr2 = false;
         if (!attr2) {

@@ -383,7 +383,6 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         StemSparseArgs sa{};
         sa.coords = coords; sa.values = values; sa.nnz = nnz; sa.n_img = n; sa.H = cfg.H; sa.W = cfg.W; sa.Cpix = cfg.in_ch;
         sa.value_mode = log_pixels; sa.noise_std = train ? noise_std : 0.f; sa.seed = seed;
-        sa.cells_y = cdiv(cfg.H, 32); sa.cells_x = cdiv(cfg.W, 32);
         stem_sparse_carve(sa, ws + L.sidx);
         sa.Wk = ws + L.wk + e.off; sa.Kp = e.Kp; sa.bias = data[s_b0];
         sa.Hc = Hc; sa.Wc = Wc; sa.Ho = b0.H; sa.Wo = b0.W;

@@ -343,8 +343,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             StemSparseArgs sa{};
             sa.coords = last_coords; sa.values = last_values; sa.nnz = last_nnz; sa.n_img = n; sa.H = cfg.H; sa.W = cfg.W; sa.Cpix = cfg.in_ch;
             sa.value_mode = last_value_mode; sa.noise_std = last_noise; sa.seed = seed;
-            sa.cells_y = cdiv(cfg.H, 32); sa.cells_x = cdiv(cfg.W, 32);
-            stem_sparse_carve(sa, ws + L.sidx);
+                stem_sparse_carve(sa, ws + L.sidx);
             sa.Wk = ws + L.wk + ef.off; sa.Kp = ef.Kp; sa.bias = data[s_b0];
             sa.Hc = Hc; sa.Wc = Wc; sa.Ho = b0.H; sa.Wo = b0.W;
             sa.sc = sc_of(n0); sa.sh = sh_of(n0); sa.sl = data[s_a0]; sa.e = e; sa.part = part;

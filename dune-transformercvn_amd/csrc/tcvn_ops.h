@@ -254,8 +254,8 @@ int stem_fwd_bf16(const ConvFwdArgs& a, hipStream_t st);
 struct StemSparseArgs {
     const int* coords; const float* values; long nnz;       // COO list [nnz][3] (image, y, x), values [nnz][Cpix]
     int n_img, H, W, Cpix, value_mode; float noise_std; uint64_t seed;
-    int cells_y, cells_x;                                    // 32 x 32-pixel bucket cells per map
-    int *cell_start, *cell_fill, *cell_hits; float4* pv;     // index (stem_sparse_carve): prefix, cursors, bucketed hit ids, preprocessed values
+    int *row_start, *row_fill; uint4* rec;                   // index (stem_sparse_carve): per (map, pixel row) prefix and cursors; 16-byte records
+                                                             // (y << 16 | x, v0 | v1 << 16 as bf16, v2 | flags, list index) bucketed by row
     const void* Wk; int Kp; const float* bias;               // conv0 weights [64][Kp] bf16 (k = tap*Cpix + c), bias fp32
     int Hc, Wc, Ho, Wo;                                      // conv0 output map, pooled map
     const float *sc, *sh, *sl;                               // BatchNorm0 (scale, shift) table, PReLU0 slope
