@@ -371,8 +371,14 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
     TCVN_CHECK(hipMemsetAsync(ws + L.zeros, 0, 1024, st));
     // Sparse-aware stem (bf16, 3 -> 64 channels, the hit list fits the index): conv0 + BN0 + PReLU0 + AvgPool straight from the COO
     // list, neither the dense map nor the conv0 output is materialised (stem_sparse.hip).  Otherwise: scatter + dense kernels.
-    static const bool dense_stem_knob = TCVN_KNOB_SET("TCVN_DENSE_STEM");     // validation builds: force the dense stem kernels (A/B, parity tests)
-    const bool sparse_stem = !dense_stem_knob && L.sidx >= 0 &&
+    // Measured on MI355X (256 prong maps / 32 event maps, round 3): inference -- index + pooled pass 0.60 / 0.27 ms against 0.97 / 0.12 ms
+    // for the dense conv0 + pooling kernels, so eval-mode forwards take the sparse stem.  Training -- the statistics pass adds 0.34 / 0.16 ms
+    // (forward at parity with the dense kernels) and the sparse backward passes (0.87 + 4.3 ms) lose clearly to the dense backward
+    // (0.40 + 0.50 ms: its weight gradient already walks the hit list), so train-mode steps keep the dense stem.  The validation build
+    // can force either (TCVN_DENSE_STEM / TCVN_SPARSE_STEM_TRAIN) for the parity tests of all four sparse passes.
+    static const bool dense_stem_knob = TCVN_KNOB_SET("TCVN_DENSE_STEM");
+    static const bool sparse_train_knob = TCVN_KNOB_SET("TCVN_SPARSE_STEM_TRAIN");
+    const bool sparse_stem = !dense_stem_knob && (!train || sparse_train_knob) && L.sidx >= 0 &&
                              stem_sparse_ok(mode, cfg.in_ch, cfg.init_ch, cfg.H, cfg.W, log_pixels, nnz, n, blocks[0].ld);
     last_sparse_stem = sparse_stem;
     last_values = values; last_value_mode = log_pixels; last_noise = train ? noise_std : 0.f;

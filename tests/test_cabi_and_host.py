@@ -36,7 +36,7 @@ def test_product_library_has_no_environment_switches():
     undefined = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in undefined
     blob = open(_lib.LIB_PATH, "rb").read()
-    for knob in (b"TCVN_DBG", b"TCVN_DISABLE_TILE", b"TCVN_XA_ONTHEFLY", b"TCVN_BWD_SERIAL", b"TCVN_POOL0_BWD_FLAT", b"TCVN_DENSE_STEM"):
+    for knob in (b"TCVN_DBG", b"TCVN_DISABLE_TILE", b"TCVN_XA_ONTHEFLY", b"TCVN_BWD_SERIAL", b"TCVN_POOL0_BWD_FLAT", b"TCVN_DENSE_STEM", b"TCVN_SPARSE_STEM_TRAIN"):
         assert knob not in blob, knob
     # ... and the Python loader binds the product library whatever the environment says (the debug build is selected only by an
     # explicit _libselect.use() call in a test child process)
