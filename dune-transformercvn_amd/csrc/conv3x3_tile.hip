@@ -312,6 +312,15 @@ size_t fwd_ring_smem() { return RING * 256 + RING * 4 + 4 * 32 * 16; }
 // The matrix pipe of the SIMD sees the same 72 MFMAs per tile, but the epilogue, the table arithmetic, the LDS waits and the DMA issue of
 // one wave now sit under the other wave's MFMAs.  Ring rows are sized from the map width (rows() + 128, multiple of 16) so that the LDS
 // also holds the two exchange buffers: 100 KB + 32 KB at W = 69.
+// phase counters of the pair kernel (validation build only): wave-cycles per phase, reported by every 16th workgroup
+#ifdef TCVN_DEBUG_KNOBS
+__device__ unsigned long long g_pair_ph[16];
+#define PAIR_T0() unsigned long long ph_t = clock64()
+#define PAIR_PH(i) do { const unsigned long long n_ = clock64(); ph[i] += n_ - ph_t; ph_t = n_; } while (0)
+#else
+#define PAIR_T0() do {} while (0)
+#define PAIR_PH(i) do {} while (0)
+#endif
 constexpr int PAIR_TBL = 1024;       // table entries (power of two > 512 + halo: an entry lives two tiles longer than its image row)
 __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdArgs g, int n_img, int ntiles, int ring) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -320,7 +329,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
     int* tbl = reinterpret_cast<int*>(smem + ring * 256);                             // [1024] pixel index of row (row-space index & 1023): an entry
                                                                                       // outlives its image row (the deferred epilogue reads it a tile later)
     float* xchg = reinterpret_cast<float*>(smem + ring * 256 + PAIR_TBL * 4);         // [2][4 pairs][16][64] role A's partial sums
-    double* red = reinterpret_cast<double*>(xchg + 2 * 4 * 16 * 64);                  // [4][32][2]
+    bf16* ctile = reinterpret_cast<bf16*>(xchg + 2 * 4 * 16 * 64);                    // [4 pairs][32][32] bf16 output tiles of the epilogue
+    double* red = reinterpret_cast<double*>(ctile + 4 * 32 * 32);                     // [4][32][2]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool roleB = wave >= 4;
@@ -337,6 +347,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
     const float bias = nok ? g.bias[r] : 0.f;
     const bool drop = g.drop_p > 0.f;
     const uint32_t dkey = drop_key(g.seed, g.stream_id);
+    // all 32 channels present and the output slice 16-B aligned: the tile leaves in 16-B stores through LDS
+    const bool vec_store = g.N == 32 && (g.n_off & 7) == 0 && (g.ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(g.Out) & 15) == 0;
     auto wrap = [&](int x) { return x >= ring ? x - ring : x; };                      // x in [0, 2 * ring)
 
     // weight fragment (tap, ks) sits at ((tap*8 + ks)*64 + lane)*8; role A keeps taps 0..4 in registers, role B taps 5..8
@@ -348,13 +360,23 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
     };
     auto dma_rows = [&](int row0, int slot0, int n) {                                 // n multiple of 4; 4 rows (1 KiB) per wave instruction, 8 waves
         const int rsub = lane >> 4, slot = lane & 15;
-        for (int rg = wave; rg * 4 < n; rg += 8) {
-            const int ring_row = wrap(slot0 + rg * 4);                                // slot0, ring multiples of 4: a group never wraps
-            const int rr = ring_row + rsub;
-            const int m = tbl[(row0 + rg * 4 + rsub) & (PAIR_TBL - 1)];
-            const char* src = m >= 0 ? reinterpret_cast<const char*>(YA + (long)m * 128) + ((slot ^ (rr & 15)) << 4) : zeros + (slot << 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(smem + ring_row * 256), 16, 0, 0);
+        // four instructions per trip with their table reads batched in front (one dependent LDS read per instruction: 1 200 cycles per
+        // wave and tile in the phase counters, 750-900 batched)
+        for (int rg0 = wave; rg0 * 4 < n; rg0 += 32) {
+            int m4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m4[j] = tbl[(row0 + (rg0 + 8 * j) * 4 + rsub) & (PAIR_TBL - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rg = rg0 + 8 * j;
+                if (rg * 4 < n) {
+                    const int ring_row = wrap(slot0 + rg * 4);                        // slot0, ring multiples of 4: a group never wraps
+                    const int rr = ring_row + rsub;
+                    const char* src = m4[j] >= 0 ? reinterpret_cast<const char*>(YA + (long)m4[j] * 128) + ((slot ^ (rr & 15)) << 4) : zeros + (slot << 4);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(smem + ring_row * 256), 16, 0, 0);
+                }
+            }
         }
     };
     if (t0 < t1) fill_rows(0, nrows4, tid, 512);
@@ -362,15 +384,21 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
     __syncthreads();
     if (t0 < t1) dma_rows(0, 0, nrows4);
 
+#ifdef TCVN_DEBUG_KNOBS
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     double s1 = 0, s2 = 0;
     f32x16 accp;                                                                      // role B: its partial sums of the previous tile
 #pragma unroll
     for (int e = 0; e < 16; ++e) accp[e] = 0.f;
     int slot_tile = 0;                                                                // ring slot of the current tile's first image row
     int slot_new = wrap(nrows4);                                                      // ring slot of the NEXT tile's first new row
-    // role B's deferred epilogue of tile `te` (its first image row sat in ring slot `slot_e`): partial sums of both waves, bias, dropout,
-    // store, statistics
-    auto epilogue = [&](int te, const f32x16& mine) {
+    // role B's deferred epilogue of tile `te`: partial sums of both waves, bias, dropout, store, statistics.  Branch-free: the first
+    // version tested `m >= 0`, the dropout group and the store path per element -- ~100 taken branches per tile, 5 460 cycles per wave and
+    // tile in the phase counters (4 000 now) -- so everything is computed for all 16 elements and selected.  With all 32 channels present the
+    // tile leaves through a bf16 tile in LDS as 16-B stores (two per lane instead of sixteen 2-byte scattered stores).
+    auto epilogue_impl = [&](auto dropc, auto vecc, int te, const f32x16& mine) {
+        constexpr bool DROP = decltype(dropc)::value, VEC = decltype(vecc)::value;
         const float* xc = xchg + (((te - t0) & 1) * 4 + pw) * 16 * 64 + lane;
         float part[16];
 #pragma unroll
@@ -378,30 +406,48 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
         int mrow[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) mrow[e] = tbl[((te - t0) * TP + q.halo + pw * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) & (PAIR_TBL - 1)];
-        long cur_grp = -1;
-        uint32_t bits = 0;
         float f1 = 0.f, f2 = 0.f;
+        bf16* ct = ctile + pw * 32 * 32;                                              // this pair's [32 positions][32 channels] bf16 tile (wave private)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = mrow[e];
-            if (m >= 0 && nok) {
-                float v = mine[e] + part[e] + bias;
-                if (drop) {
-                    if ((m >> 1) != cur_grp) { cur_grp = m >> 1; bits = drop_bits(dkey, m, r, g.N); }
-                    v *= drop_pick(bits, m, g.drop_p);
-                }
-                const bf16 o = f2bf(v);
-                Out[(long)m * g.ldo + g.n_off + r] = o;
-                const float x = bf2f(o);
-                f1 += x; f2 = fmaf(x, x, f2);
+            const bool ok = m >= 0 && nok;
+            float v = mine[e] + part[e] + bias;
+            if (DROP) {
+                const int mm = m < 0 ? 0 : m;
+                v *= drop_pick(drop_bits(dkey, mm, r, g.N), mm, g.drop_p);
             }
+            const bf16 o = ok ? f2bf(v) : (bf16)0;
+            const float x = bf2f(o);                                                  // 0 for padding positions / absent channels
+            f1 += x; f2 = fmaf(x, x, f2);
+            if (VEC) ct[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = o;
+            else if (ok) Out[(long)m * g.ldo + g.n_off + r] = o;
         }
         s1 += (double)f1; s2 += (double)f2;
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                                             // 32 positions x 64 B = 128 chunks of 16 B, two per lane
+                const int c = lane + 64 * i, pos = c >> 2, chunk = c & 3;
+                const int m = tbl[((te - t0) * TP + q.halo + pw * 32 + pos) & (PAIR_TBL - 1)];
+                const u16x8 v8 = *reinterpret_cast<const u16x8*>(ct + pos * 32 + chunk * 8);
+                if (m >= 0) *reinterpret_cast<u16x8*>(Out + (long)m * g.ldo + g.n_off + chunk * 8) = v8;
+            }
+        }
+    };
+    auto epilogue = [&](int te, const f32x16& mine) {                                  // uniform dispatch, once per tile
+        if (drop) {
+            if (vec_store) epilogue_impl(std::true_type{}, std::true_type{}, te, mine);
+            else epilogue_impl(std::true_type{}, std::false_type{}, te, mine);
+        } else {
+            if (vec_store) epilogue_impl(std::false_type{}, std::true_type{}, te, mine);
+            else epilogue_impl(std::false_type{}, std::false_type{}, te, mine);
+        }
     };
 
     // one multiply pass: NT taps starting at tap `tap_first` over the 32 positions of this pair, image of the tile in ring slot `slot_t`.
-    // The A fragments travel LDS -> registers four k-steps (half a tap) ahead of the MFMAs that consume them: two register groups of
-    // four fragments; without the prefetch every MFMA waits for its own ds_read (measured: 243 us instead of 277 for block 1 only).
+    // The A fragments travel LDS -> registers four k-steps (half a tap) ahead of the MFMAs that consume them (two register groups of four
+    // fragments); the lgkmcnt wait is placed by hand BEFORE the next group's reads are issued -- hipcc would sink the reads next to their
+    // uses or put the wait behind the new reads.  (Two accumulator chains with two-fragment groups measured slower: 212 vs 197 us.)
     auto multiply = [&](auto& bwr, auto ntc, int tap_first, int slot_t, f32x16& acc) {
         constexpr int NT = decltype(ntc)::value, NG = NT * 2;
 #pragma unroll
@@ -423,10 +469,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
         load_group(0, af[0]);
 #pragma unroll
         for (int gI = 0; gI < NG; ++gI) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0) BEFORE the next group's reads are issued: this group's fragments (read four
-            __builtin_amdgcn_sched_barrier(0);          // MFMAs ago) are in; placed by hand because hipcc would put the wait behind the new reads
+            __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0): this group's fragments (read four MFMAs ago) are in
+            __builtin_amdgcn_sched_barrier(0);
             if (gI + 1 < NG) load_group(gI + 1, af[(gI + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);          // keep the four reads ahead of the four MFMAs (hipcc otherwise sinks them next to their uses)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[gI & 1][i], bwr[gI * 4 + i], acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -437,17 +483,23 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
         bf16x8_t bw[40];
 #pragma unroll
         for (int i = 0; i < 40; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + i * 512);
+        PAIR_T0();
         for (int t = t0; t < t1; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's share of tile t's rows has landed
+            PAIR_PH(0);
             __syncthreads();                                                          // ... everybody's; tile t-1's MFMAs are done; xchg / tbl of the last phase visible
+            PAIR_PH(1);
             if (t + 1 < t1) dma_rows(nrows4 + (t - t0) * TP, slot_new, TP);            // the next tile's 128 new rows travel under this tile's work
+            PAIR_PH(2);
             f32x16 acc;
             multiply(bw, std::integral_constant<int, 5>{}, 0, slot_tile, acc);
             float* xc = xchg + (((t - t0) & 1) * 4 + pw) * 16 * 64 + lane;
 #pragma unroll
             for (int e = 0; e < 16; ++e) xc[e * 64] = acc[e];
+            PAIR_PH(3);
             // table of the rows the NEXT iteration will fetch (tile t + 2's new rows), by the 256 role-A threads
             if (t + 2 < t1) fill_rows(nrows4 + (t - t0 + 1) * TP, TP, tid, 256);
+            PAIR_PH(4);
             slot_tile = wrap(slot_tile + TP);
             slot_new = wrap(slot_new + TP);
         }
@@ -455,16 +507,27 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
         bf16x8_t bw[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + (40 + i) * 512);
+        PAIR_T0();
         for (int t = t0; t < t1; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // DMA share landed, stores of the last epilogue left
+            PAIR_PH(8);
             __syncthreads();
+            PAIR_PH(9);
             if (t + 1 < t1) dma_rows(nrows4 + (t - t0) * TP, slot_new, TP);
+            PAIR_PH(10);
             if (t > t0) epilogue(t - 1, accp);                                         // finish tile t-1 while role A multiplies tile t
+            PAIR_PH(11);
             multiply(bw, std::integral_constant<int, 4>{}, 5, slot_tile, accp);
+            PAIR_PH(12);
             slot_tile = wrap(slot_tile + TP);
             slot_new = wrap(slot_new + TP);
         }
     }
+#ifdef TCVN_DEBUG_KNOBS
+    if (lane == 0 && (blockIdx.x & 15) == 0)                  // every 16th workgroup reports (the atomics of all of them cost ~70 us per launch)
+        for (int i = 0; i < 16; ++i)
+            if (ph[i]) atomicAdd(&g_pair_ph[i], ph[i]);
+#endif
     __syncthreads();                                                                  // the last tile's exchange buffer is complete
     if (roleB && t1 > t0) epilogue(t1 - 1, accp);
     if (g.part != nullptr) {
@@ -482,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
     }
 }
 int fwd_pair_ring(const PadGeom& q) { return (int)((((q.rows() + 3) & ~3) + TP + 15) & ~15); }
-size_t fwd_pair_smem(const PadGeom& q) { const size_t ring = fwd_pair_ring(q); return ring * 256 + PAIR_TBL * 4 + 2 * 4 * 16 * 64 * 4 + 4 * 32 * 16; }
+size_t fwd_pair_smem(const PadGeom& q) { const size_t ring = fwd_pair_ring(q); return ring * 256 + PAIR_TBL * 4 + 2 * 4 * 16 * 64 * 4 + 4 * 32 * 32 * 2 + 4 * 32 * 16; }
 
 
 size_t fwd_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return 2 * r4 * 256 + 3 * r4 * 4 + 4 * 32 * 16; }
@@ -1139,3 +1202,11 @@ int conv3x3_dgrad_tile(const ConvDgradArgs& a, hipStream_t st) {
 }
 
 }  // namespace tcvn
+
+#ifdef TCVN_DEBUG_KNOBS
+extern "C" void tcvn_debug_pair_phases(unsigned long long* out16, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(tcvn::g_pair_ph), 16 * 8);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(tcvn::g_pair_ph), z, 16 * 8); }
+}
+#endif
