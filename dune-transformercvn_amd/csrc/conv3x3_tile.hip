@@ -358,17 +358,17 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
     auto fill_rows = [&](int row0, int n, int t, int nt) {                            // by threads [t, t + nt)
         for (int i = t; i < n; i += nt) tbl[(row0 + i) & (PAIR_TBL - 1)] = pix_of(q, g_org + row0 + i, invWp, invHp);
     };
-    auto dma_rows = [&](int row0, int slot0, int n) {                                 // n multiple of 4; 4 rows (1 KiB) per wave instruction, 8 waves
-        const int rsub = lane >> 4, slot = lane & 15;
+    auto dma_rows = [&](int row0, int slot0, int n, int w0, int nw) {                 // n multiple of 4; 4 rows (1 KiB) per wave instruction, issued by
+        const int rsub = lane >> 4, slot = lane & 15;                                 // wave w0 of nw
         // four instructions per trip with their table reads batched in front (one dependent LDS read per instruction: 1 200 cycles per
         // wave and tile in the phase counters, 750-900 batched)
-        for (int rg0 = wave; rg0 * 4 < n; rg0 += 32) {
+        for (int rg0 = w0; rg0 * 4 < n; rg0 += 4 * nw) {
             int m4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m4[j] = tbl[(row0 + (rg0 + 8 * j) * 4 + rsub) & (PAIR_TBL - 1)];
+            for (int j = 0; j < 4; ++j) m4[j] = tbl[(row0 + (rg0 + nw * j) * 4 + rsub) & (PAIR_TBL - 1)];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int rg = rg0 + 8 * j;
+                const int rg = rg0 + nw * j;
                 if (rg * 4 < n) {
                     const int ring_row = wrap(slot0 + rg * 4);                        // slot0, ring multiples of 4: a group never wraps
                     const int rr = ring_row + rsub;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
     if (t0 < t1) fill_rows(0, nrows4, tid, 512);
     if (t0 + 1 < t1) fill_rows(nrows4, TP, tid, 512);
     __syncthreads();
-    if (t0 < t1) dma_rows(0, 0, nrows4);
+    if (t0 < t1) dma_rows(0, 0, nrows4, wave, 8);
 
 #ifdef TCVN_DEBUG_KNOBS
     unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
         const float* xc = xchg + (((te - t0) & 1) * 4 + pw) * 16 * 64 + lane;
         float part[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) part[e] = xc[e * 64];
+        for (int e = 0; e < 16; ++e) part[e] = TCVN_DBG_BIT(g.dbg, 512) ? 0.f : xc[e * 64];
         int mrow[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) mrow[e] = tbl[((te - t0) * TP + q.halo + pw * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) & (PAIR_TBL - 1)];
@@ -415,12 +415,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
             float v = mine[e] + part[e] + bias;
             if (DROP) {
                 const int mm = m < 0 ? 0 : m;
-                v *= drop_pick(drop_bits(dkey, mm, r, g.N), mm, g.drop_p);
+                v *= drop_pick(drop_bits32(dkey, mm, r, g.N), mm, g.drop_p);          // (the launcher checks pixels * N < 2^32)
             }
             const bf16 o = ok ? f2bf(v) : (bf16)0;
             const float x = bf2f(o);                                                  // 0 for padding positions / absent channels
             f1 += x; f2 = fmaf(x, x, f2);
-            if (VEC) ct[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = o;
+            if (VEC) { if (!TCVN_DBG_BIT(g.dbg, 256)) ct[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = o; }
             else if (ok) Out[(long)m * g.ldo + g.n_off + r] = o;
         }
         s1 += (double)f1; s2 += (double)f2;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
                 const int c = lane + 64 * i, pos = c >> 2, chunk = c & 3;
                 const int m = tbl[((te - t0) * TP + q.halo + pw * 32 + pos) & (PAIR_TBL - 1)];
                 const u16x8 v8 = *reinterpret_cast<const u16x8*>(ct + pos * 32 + chunk * 8);
-                if (m >= 0) *reinterpret_cast<u16x8*>(Out + (long)m * g.ldo + g.n_off + chunk * 8) = v8;
+                if (m >= 0 && !TCVN_DBG_BIT(g.dbg, 128)) *reinterpret_cast<u16x8*>(Out + (long)m * g.ldo + g.n_off + chunk * 8) = v8;
             }
         }
     };
@@ -489,8 +489,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
             PAIR_PH(0);
             __syncthreads();                                                          // ... everybody's; tile t-1's MFMAs are done; xchg / tbl of the last phase visible
             PAIR_PH(1);
-            if (t + 1 < t1) dma_rows(nrows4 + (t - t0) * TP, slot_new, TP);            // the next tile's 128 new rows travel under this tile's work
-            PAIR_PH(2);
+            if (t + 1 < t1) dma_rows(nrows4 + (t - t0) * TP, slot_new, TP, pw, 4);     // the next tile's 128 new rows travel under this tile's work:
+            PAIR_PH(2);                                                                // issued by role A alone, so that role B's stores do not queue behind loads
             f32x16 acc;
             multiply(bw, std::integral_constant<int, 5>{}, 0, slot_tile, acc);
             float* xc = xchg + (((t - t0) & 1) * 4 + pw) * 16 * 64 + lane;
@@ -507,13 +507,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
         bf16x8_t bw[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + (40 + i) * 512);
+        if (!TCVN_DBG_BIT(g.dbg, 1024)) __builtin_amdgcn_s_setprio(1);     // the second-dispatched half loses every issue arbitration otherwise
         PAIR_T0();
         for (int t = t0; t < t1; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // DMA share landed, stores of the last epilogue left
             PAIR_PH(8);
             __syncthreads();
             PAIR_PH(9);
-            if (t + 1 < t1) dma_rows(nrows4 + (t - t0) * TP, slot_new, TP);
             PAIR_PH(10);
             if (t > t0) epilogue(t - 1, accp);                                         // finish tile t-1 while role A multiplies tile t
             PAIR_PH(11);
@@ -1095,7 +1095,7 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
     ConvFwdArgs b = a;
     static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
     b.dbg = dbg;
-    if (fwd_pair_smem(q) <= 160 * 1024 && 4 * TP + q.halo + q.Wp + 1 < PAIR_TBL && !TCVN_DBG_BIT(dbg, 32) && !TCVN_DBG_BIT(dbg, 64)) {   // two waves per SIMD, taps split (TCVN_DBG=64: one-wave ring kernel)
+    if (fwd_pair_smem(q) <= 160 * 1024 && 4 * TP + q.halo + q.Wp + 1 < PAIR_TBL && (long)a.M * a.N < (1L << 32) && !TCVN_DBG_BIT(dbg, 32) && !TCVN_DBG_BIT(dbg, 64)) {   // two waves per SIMD, taps split (TCVN_DBG=64: one-wave ring kernel)
         static bool attr3 = false;
         if (!attr3) {
             TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_fwd_pair_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -102,6 +102,12 @@ __device__ __forceinline__ uint32_t drop_bits(uint32_t key, long m, int n, int N
     const uint64_t grp = (uint64_t)(m >> 1) * (uint64_t)N + (uint64_t)n;
     return lowbias32(((uint32_t)grp * 0x9E3779B1u) ^ key ^ ((uint32_t)(grp >> 32) * 0x85ebca77u));
 }
+// the same hash for slices whose group index (pixels/2 * N + n) fits 32 bits (every realistic launch: the launchers check pixels * N < 2^32):
+// the high word of the group index is zero, so its term drops out and the 64-bit multiply-add becomes a 32-bit one
+__device__ __forceinline__ uint32_t drop_bits32(uint32_t key, int m, int n, int N) {
+    const uint32_t grp = (uint32_t)(m >> 1) * (uint32_t)N + (uint32_t)n;
+    return lowbias32((grp * 0x9E3779B1u) ^ key);
+}
 __device__ __forceinline__ float drop_pick(uint32_t bits, long m, float p) {
     const uint32_t draw = (m & 1) ? (bits >> 16) : (bits & 0xffffu);
     return draw >= (uint32_t)(p * 65536.0f + 0.5f) ? 1.f / (1.f - p) : 0.f;
