@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
             const int n = ec * 8 + j;
             if (m >= 0 && n < e.N) {
                 t = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
-                if (drop) t *= drop_pick(drop_bits(dkey, m, n, e.N), m, e.drop_p);
+                if (drop) t *= drop_pick(drop_bits32(dkey, m, n, e.N), m, e.drop_p);      // (pixels * N < 2^32: conv3x3_wgrad_tile_ok)
             }
             o[j] = f2bf(t);
             bsum[j] += bf2f(o[j]);
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float v = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
-                    if (drop) v *= drop_pick(drop_bits(dkey, m, ec * 8 + j, e.N), m, e.drop_p);
+                    if (drop) v *= drop_pick(drop_bits32(dkey, m, ec * 8 + j, e.N), m, e.drop_p);      // (pixels * N < 2^32: conv3x3_dgrad_tile_ok)
                     o[j] = f2bf(v);
                 }
             }
@@ -1133,7 +1133,7 @@ bool conv3x3_wgrad_tile_ok(const ConvWgradArgs& a) {
     if (fa.Aact == nullptr || fa.zeros == nullptr || (a.e.ldg & 7) || (a.e.ldx & 7) || (a.e.c_off & 1)) return false;
     if (fa.M % (fa.H * fa.W) != 0) return false;
     const PadGeom q(fa.M / (fa.H * fa.W), fa.H, fa.W);
-    return q.gtot < (1L << 24) && wgrad_smem(q) <= 160 * 1024;
+    return q.gtot < (1L << 24) && wgrad_smem(q) <= 160 * 1024 && (long)fa.M * a.e.N < (1L << 32);
 }
 
 int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st) {
@@ -1150,6 +1150,8 @@ int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st) {
     if (a.slab == nullptr || (long)nb * (9 * 128 * 32 + 32) * 4 > a.slab_bytes || a.dbias == nullptr) return -3;
     {
         ProfScope ps("k_conv3x3_wgrad_bf16", 2.0 * a.fa.M * (double)a.e.N * a.fa.K, (double)a.fa.M * 2.0 * (a.fa.C + 2 * a.e.N), st);   // YA + (G, x) slices
+        // (a ring variant of this kernel -- consecutive tiles, 128 new image rows per step instead of the whole 70 KB image, batched table
+        //  reads -- measured 378 us against 360-375 us for block 1: the image re-fetch comes from L2 and is not what bounds it)
         hipLaunchKernelGGL(k_conv3x3_wgrad_bf16, dim3(nb), dim3(256), wgrad_smem(q), st, a, n_img, ntiles,
                            (nb >= 8 && nb % 8 == 0) ? 1 : 0);
         TCVN_LAUNCH_CHECK();
@@ -1170,7 +1172,7 @@ bool conv3x3_dgrad_tile_ok(const ConvDgradArgs& a) {
     if (a.Wfrag == nullptr || a.accumulate || a.ldxin != 128 || a.ldgo != 128) return false;
     if ((a.e.ldg & 7) || (a.e.ldx & 7) || (a.e.c_off & 1) || a.M % (a.H * a.W) != 0) return false;
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
-    return q.gtot < (1L << 24);
+    return q.gtot < (1L << 24) && (long)a.M * a.e.N < (1L << 32);
 }
 int conv3x3_dgrad_tile_nblk(const ConvDgradArgs& a) {
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);

@@ -9,12 +9,13 @@ the gfx950 engine (csrc/densenet.hip) which runs the whole stack as fused implic
 from __future__ import annotations
 
 from collections import OrderedDict
-from typing import Dict, Sequence
+from typing import Dict, List, Sequence
 
 import torch
 from torch import Tensor, nn
 
 from transformercvn.hip.pixels import SparsePixels
+from transformercvn.hip import torch_ops  # noqa: F401  (registers tcvn::densenet_embed with the dispatcher; no GPU needed)
 
 
 def _holder(**mods: nn.Module) -> nn.Sequential:
@@ -57,9 +58,14 @@ class Transition(nn.Sequential):
 
 
 class DenseNet(nn.Module):
+    __constants__ = ["export_ops"]       # a script-time constant: the branch not taken is not compiled (the ATen export holds no tcvn:: node)
+
     def __init__(self, input_features: int, output_features: int, initial_latent_features: int = 64, growth_rate: int = 32,
                  batch_norm_size: int = 4, block_config: Sequence[int] = (6, 12, 24, 16), dropout: float = 0.0) -> None:
         super().__init__()
+        self.export_ops = False
+        self.op_tensors = []
+        self.op_cfg = []
         self.hyper = dict(in_ch=input_features, out_dim=output_features, init_ch=initial_latent_features, growth=growth_rate,
                           bn_size=batch_norm_size, layers=list(block_config), dropout=float(dropout))
         c = initial_latent_features
@@ -104,8 +110,19 @@ class DenseNet(nn.Module):
         Under ``torch.jit.script`` (CreateCompiled.ipynb cells 6-14: TorchScript export for CPU inference in LArSoft) the holder
         modules are real torch modules with the reference's parameters, so the exported graph runs them through ATen."""
         if torch.jit.is_scripting():
+            if self.export_ops:       # one dispatcher operator: CPU tensors -> ATen, GPU tensors -> libtcvn_hip.so (hip/torch_ops.py)
+                return torch.ops.tcvn.densenet_embed(x, self.op_tensors, self.op_cfg)
             return self.output_block(self.condense(self.features(x)))
         return self._hip_forward(x)
+
+    def use_export_ops(self, on: bool = True) -> None:
+        """Call before torch.jit.script: the scripted embedder becomes one ``tcvn::densenet_embed`` node over this module's parameters
+        (eval mode) instead of the ATen graph of the holder modules."""
+        self.export_ops = bool(on)
+        if on:
+            self.op_tensors, self.op_cfg = torch_ops.embedder_tensors(self)
+        else:
+            self.op_tensors, self.op_cfg = [], []
 
     @torch.jit.unused
     def _hip_forward(self, x: Tensor) -> Tensor:
@@ -128,3 +145,7 @@ class DenseNet(nn.Module):
             if self.training:
                 torch._foreach_add_([m.num_batches_tracked for m in self.batch_norms()], 1)
         return out
+
+
+# TorchScript attribute types of the operator export (real types: this module uses postponed annotations, which TorchScript cannot resolve)
+DenseNet.__annotations__ = {"op_tensors": List[Tensor], "op_cfg": List[int]}

@@ -107,6 +107,16 @@ class NeutrinoBaseNetwork(nn.Module):
         register(self.encoder, self)
         self.pixel_shape: Tuple[int, int] = (400, 280)
 
+    def prepare_export(self, use_ops: bool = False):
+        """TorchScript export (CreateCompiled.ipynb cells 6-14).  use_ops=False (default): every stage scripts its ATen branch -- the
+        file loads anywhere.  use_ops=True: the two pixel-map embedders script to the registered operator tcvn::densenet_embed, which
+        runs ATen on CPU tensors and the gfx950 kernels on GPU tensors (needs `import transformercvn` in the loading process)."""
+        for emb in (self.prong_embedding.prong_pixel_embedding, self.prong_embedding.event_pixel_embedding):
+            if hasattr(emb, "use_export_ops"):
+                emb.hip_mode = self.hip_runtime().mode
+                emb.use_export_ops(use_ops)
+        return self
+
     def hip_runtime(self):
         """Lazily created fused runtime.  Precision: ``options.hip_precision`` ('fp32' parity mode or 'bf16') or, when the option
         file does not name it, what the Lightning trainer was given (``train.py -fp16`` -> precision 16 -> bf16 engines; see

@@ -88,3 +88,32 @@ def test_eager_cpu_call_still_fails_loudly():
     model = build_trainer(cfg, None, device=None)
     with pytest.raises(RuntimeError):
         model.network(*_dense_inputs(cfg, batch))
+
+
+def test_scripted_network_with_registered_operator_on_cpu():
+    """SURVEY.md 8f-3: the embedders as ONE dispatcher operator (tcvn::densenet_embed, transformercvn/hip/torch_ops.py).  On CPU
+    tensors the scripted module dispatches to the operator's ATen kernel: reference goldens, save / load round trip, and the graph
+    really holds the operator."""
+    cfg, over, batch, g = load_case("small_b3")
+    model = build_trainer(cfg, O.fill_state(cfg, int(g["weight_seed"])), device=None)
+    model.eval()
+    scripted = torch.jit.script(model.network.prepare_export(use_ops=True))
+    assert "tcvn::densenet_embed" in str(scripted.prong_embedding.prong_pixel_embedding.graph)
+    with torch.no_grad():
+        ev, pr = scripted(*_dense_inputs(cfg, batch))
+    assert rel_err(ev, g["eval_event_logits"]) < 1e-4 and rel_err(pr, g["eval_prong_logits"]) < 1e-4
+    buf = io.BytesIO()
+    torch.jit.save(scripted, buf)
+    buf.seek(0)
+    loaded = torch.jit.load(buf)
+    with torch.no_grad():
+        ev2, pr2 = loaded(*_dense_inputs(cfg, batch))
+    assert torch.equal(ev, ev2) and torch.equal(pr, pr2)
+    # the operator is callable directly, and the default export is still the pure ATen graph
+    emb = model.network.prong_embedding.prong_pixel_embedding
+    px = O.preprocess_pixels(cfg, batch[5], batch[6], False)
+    with torch.no_grad():
+        direct = torch.ops.tcvn.densenet_embed(px, emb.op_tensors, emb.op_cfg)
+    assert direct.shape == (int(batch[7].sum()), O.embed_dims(cfg)[0])
+    plain = torch.jit.script(model.network.prepare_export(use_ops=False))
+    assert "tcvn::" not in str(plain.prong_embedding.prong_pixel_embedding.graph)
