@@ -24,6 +24,12 @@ LABELS = {            # bench.py label -> substring of the demangled kernel name
     "k_gemm_tn_bf16<conv1>": "k_gemm_tn_bf16<0>",
     "k_gemm_nt_bf16<fwd1x1>": "k_gemm_nt_bf16<0, ",
     "k_encoder_fwd": "k_encoder_fwd",
+    # --sdxl embedder: bench labels name the operator, rocprof the kernel that served it (k_sconv3_c64 runs the forward AND the data
+    # gradient of the 64->64 layers: the average over both is attributed to either label)
+    "k_sconv_fwd<bf16,3x3/1,64->64>": "k_sconv3_c64(",
+    "k_sconv_dgrad<bf16,3x3/1,64->64>": "k_sconv3_c64(",
+    "k_sconv_wgrad<bf16,3x3/1,64->64>": "k_sconv3_c64_wgrad<1, false>",
+    "k_sconv3_g": "k_sconv3_g(",
     "k_encoder_bwd": "k_encoder_bwd",
 }
 
