@@ -1,0 +1,23 @@
+#!/bin/bash
+# Kernel trace of two serialised bf16 steps, kept as CSV for tools/per_block.py (per dense block x kernel time table).
+# usage (GPU box): bash tools/per_block_trace.sh [extra bench flags]
+set -u
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/perblock
+rm -rf $OUT && mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT/t -o t --output-format csv -- python3 $ROOT/bench.py --precision bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-sdxl --no-profile --no-bwd-overlap "$@" > $OUT/bench.json 2> $OUT/err
+ls -la $OUT/t
+python3 - <<PY
+import csv,glob
+f=glob.glob("$OUT/t/*kernel_trace.csv")[0]
+rows=list(csv.DictReader(open(f)))
+print(len(rows), rows[0].keys())
+keep=["Kernel_Name","Start_Timestamp","End_Timestamp","Grid_Size_X","Grid_Size_Y","Grid_Size_Z","Workgroup_Size_X","Stream_Id","Queue_Id"]
+keep=[k for k in keep if k in rows[0]]
+w=csv.writer(open("$OUT/trace_small.csv","w"))
+w.writerow(keep)
+for r in rows: w.writerow([r[k].replace("tcvn::(anonymous namespace)::","") for k in keep])
+PY
+rm -rf $OUT/t
+ls -la $OUT
