@@ -153,63 +153,79 @@ __global__ void k_head_pool(const HeadPoolArgs a) {
 
 // ---- materialised activation: Out = bf16(prelu(X*sc + sh, sl)), 8 channels (16 B) per thread ------------------------
 // Feeds the bf16 3x3 tile kernels, whose LDS images are then filled by LDS-DMA without touching the VALU.
+// A thread keeps ONE 8-channel chunk for the whole launch (its 24 table values stay in registers) and walks pixels: a block pass
+// covers 256/cpr pixels x cpr chunks, consecutive lanes = consecutive 16-B chunks of a row.  (Before: a flat index over (pixel, chunk)
+// with a 64-bit division and 24 table loads per 16 B moved.)
+struct ChanTab { float sc[8], sh[8], sl[8]; };
+__device__ __forceinline__ ChanTab chan_tab(const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ sl, int c, int C) {
+    ChanTab t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const bool ok = c + j < C; t.sc[j] = ok ? sc[c + j] : 0.f; t.sh[j] = ok ? sh[c + j] : 0.f; t.sl[j] = ok ? sl[c + j] : 0.f; }
+    return t;
+}
 __global__ __launch_bounds__(256) void k_act_bf16(const ActArgs a) {
-    const bf16* X = reinterpret_cast<const bf16*>(a.X);
-    bf16* O = reinterpret_cast<bf16*>(a.Out);
+    const bf16* __restrict__ X = reinterpret_cast<const bf16*>(a.X);
+    bf16* __restrict__ O = reinterpret_cast<bf16*>(a.Out);
     const int cpr = (a.C + 7) >> 3;                            // chunks per row; the tail chunk is zero padded in Out
-    const long total = (long)a.M * cpr;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long m = i / cpr;
-        const int c = (int)(i - m * cpr) * 8;
-        const u16x8 v = *reinterpret_cast<const u16x8*>(X + m * a.ldx + c);      // row stride ldx >= round_up(C, 8)
-        u16x8 o;
-        if (c + 8 <= a.C) {
+    const int ppb = 256 / cpr;                                 // pixels per block pass (launcher: cpr <= 256)
+    const int q = threadIdx.x / cpr, c = (threadIdx.x - q * cpr) * 8;
+    if (q >= ppb) return;
+    const ChanTab t = chan_tab(a.sc, a.sh, a.sl, c, a.C);
+    const bool tail = c + 8 > a.C;
+    const long stride = (long)gridDim.x * ppb;
+    long m = (long)blockIdx.x * ppb + q;
+    for (; m + stride < a.M; m += 2 * stride) {                // two rows per trip: two loads in flight per thread
+        const u16x8 v0 = *reinterpret_cast<const u16x8*>(X + m * a.ldx + c);      // row stride ldx >= round_up(C, 8)
+        const u16x8 v1 = *reinterpret_cast<const u16x8*>(X + (m + stride) * a.ldx + c);
+        u16x8 o0, o1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j]));
-        } else {                                               // tail chunk of a row: channels >= C are written as zeros
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                o[j] = c + j < a.C ? f2bf(prelu(fmaf(bf2f(v[j]), a.sc[c + j], a.sh[c + j]), a.sl[c + j])) : (bf16)0;
+        for (int j = 0; j < 8; ++j) {
+            o0[j] = f2bf(prelu(fmaf(bf2f(v0[j]), t.sc[j], t.sh[j]), t.sl[j]));
+            o1[j] = f2bf(prelu(fmaf(bf2f(v1[j]), t.sc[j], t.sh[j]), t.sl[j]));
         }
-        *reinterpret_cast<u16x8*>(O + m * a.ldo + c) = o;
+        if (tail) {                                            // channels >= C are written as zeros (v may hold anything there)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (c + j >= a.C) { o0[j] = 0; o1[j] = 0; }
+        }
+        *reinterpret_cast<u16x8*>(O + m * a.ldo + c) = o0;
+        *reinterpret_cast<u16x8*>(O + (m + stride) * a.ldo + c) = o1;
+    }
+    if (m < a.M) {
+        const u16x8 v0 = *reinterpret_cast<const u16x8*>(X + m * a.ldx + c);
+        u16x8 o0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o0[j] = (!tail || c + j < a.C) ? f2bf(prelu(fmaf(bf2f(v0[j]), t.sc[j], t.sh[j]), t.sl[j])) : (bf16)0;
+        *reinterpret_cast<u16x8*>(O + m * a.ldo + c) = o0;
     }
 }
 
 // ---- pooled activation in front of a transition conv: XP[img,ho,wo,c] = 1/4 sum_{2x2} prelu(bn(D)) ------------------------
+// same thread mapping; 32-bit pixel arithmetic (launcher: n_img*Ho*Wo < 2^31)
 __global__ __launch_bounds__(256) void k_act_pool_bf16(const ActPoolArgs a) {
-    const bf16* X = reinterpret_cast<const bf16*>(a.X);
-    bf16* O = reinterpret_cast<bf16*>(a.Out);
+    const bf16* __restrict__ X = reinterpret_cast<const bf16*>(a.X);
+    bf16* __restrict__ O = reinterpret_cast<bf16*>(a.Out);
     const int Ho = a.Hin / 2, Wo = a.Win / 2, cpr = (a.C + 7) >> 3;
-    const long total = (long)a.n_img * Ho * Wo * cpr;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long mo = i / cpr;
-        const int c = (int)(i - mo * cpr) * 8;
-        const int wo = (int)(mo % Wo);
-        const int ho = (int)((mo / Wo) % Ho);
-        const long img = mo / ((long)Wo * Ho);
-        const long p00 = (img * a.Hin + 2 * ho) * a.Win + 2 * wo;
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        float sc[8], sh[8], sl[8];
-        if (c + 8 <= a.C) {
+    const int ppb = 256 / cpr;
+    const int q = threadIdx.x / cpr, c = (threadIdx.x - q * cpr) * 8;
+    if (q >= ppb) return;
+    const ChanTab t = chan_tab(a.sc, a.sh, a.sl, c, a.C);
+    const unsigned total = (unsigned)a.n_img * Ho * Wo, stride = gridDim.x * ppb;
+    for (unsigned mo = blockIdx.x * ppb + q; mo < total; mo += stride) {
+        const unsigned row = mo / Wo, wo = mo - row * Wo;       // row = img*Ho + ho
+        const unsigned img = row / Ho, ho = row - img * Ho;
+        const long p00 = ((long)img * a.Hin + 2 * ho) * a.Win + 2 * wo;
+        u16x8 v[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { sc[j] = a.sc[c + j]; sh[j] = a.sh[c + j]; sl[j] = a.sl[c + j]; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const bool ok = c + j < a.C; sc[j] = ok ? a.sc[c + j] : 0.f; sh[j] = ok ? a.sh[c + j] : 0.f; sl[j] = ok ? a.sl[c + j] : 0.f; }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const u16x8 v = *reinterpret_cast<const u16x8*>(X + (p00 + (t >> 1) * a.Win + (t & 1)) * a.ldx + c);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float y = prelu(fmaf(bf2f(v[j]), sc[j], sh[j]), sl[j]);
-                acc[j] += c + j < a.C ? y : 0.f;              // channels >= C may hold anything (never written): select, not multiply
-            }
-        }
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u16x8*>(X + (p00 + (k >> 1) * a.Win + (k & 1)) * a.ldx + c);
         u16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j] * 0.25f);
-        *reinterpret_cast<u16x8*>(O + mo * a.ldo + c) = o;
+        for (int j = 0; j < 8; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc += prelu(fmaf(bf2f(v[k][j]), t.sc[j], t.sh[j]), t.sl[j]);
+            o[j] = c + j < a.C ? f2bf(acc * 0.25f) : (bf16)0;    // channels >= C may hold anything (never written): select, not multiply
+        }
+        *reinterpret_cast<u16x8*>(O + (long)mo * a.ldo + c) = o;
     }
 }
 
@@ -350,17 +366,21 @@ int head_pool_fwd(const HeadPoolArgs& a, hipStream_t st) {
 
 int act_bf16(const ActArgs& a, hipStream_t st) {
     if ((a.ldx & 7) || (a.ldo & 7) || a.ldx < ((a.C + 7) & ~7) || a.ldo < ((a.C + 7) & ~7)) return -2;
-    const long total = (long)a.M * ((a.C + 7) >> 3);
-    const long g = (total + 255) / 256;
-    hipLaunchKernelGGL(k_act_bf16, dim3((unsigned)(g < 4096 ? g : 4096)), dim3(256), 0, st, a);
+    const int cpr = (a.C + 7) >> 3;
+    if (cpr > 256) return -2;
+    const long g = (a.M + 2 * (256 / cpr) - 1) / (2 * (256 / cpr));                 // a thread handles >= 2 rows where there are that many
+    hipLaunchKernelGGL(k_act_bf16, dim3((unsigned)(g < 4096 ? (g < 1 ? 1 : g) : 4096)), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
 }
 
 int act_pool_bf16(const ActPoolArgs& a, hipStream_t st) {
     if ((a.ldx & 7) || (a.ldo & 7) || a.ldx < ((a.C + 7) & ~7) || a.ldo < ((a.C + 7) & ~7)) return -2;
-    const long total = (long)a.n_img * (a.Hin / 2) * (a.Win / 2) * ((a.C + 7) >> 3);
-    const long g = (total + 255) / 256;
+    const int cpr = (a.C + 7) >> 3;
+    const long px = (long)a.n_img * (a.Hin / 2) * (a.Win / 2);
+    if (cpr > 256 || px >= (1L << 31) - 4096L * 256) return -2;
+    if (px <= 0) return 0;
+    const long g = (px + 256 / cpr - 1) / (256 / cpr);
     hipLaunchKernelGGL(k_act_pool_bf16, dim3((unsigned)(g < 4096 ? g : 4096)), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;

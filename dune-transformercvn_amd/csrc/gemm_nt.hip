@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
         // EPI_DGRAD: the epilogue's x / G rows of this tile are requested now, all at once, so that they travel under the
         // MFMA phase and next to the A prefetch (a load issued inside the epilogue loop cannot pass the G store of the
         // previous row group -- same base pointer -- and every row group would pay a full HBM round trip)
-        constexpr bool PREF = EPI == EPI_DGRAD && ROWS == 128;      // with two workgroups per CU the partner hides the latency
+        constexpr bool PREF = EPI == EPI_DGRAD && (ROWS == 128 || MAXKS <= 8);     // 32 registers at 64 rows: the 16-k-step variant has none to spare
         u16x8 pxv[PREF ? ROWS / 16 : 1], pgv[PREF ? ROWS / 16 : 1];
         if (PREF && col_ok) {
 #pragma unroll
@@ -174,9 +174,65 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
             for (int e = 0; e < 16; ++e) Cs[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CLD + wave * 32 + r] = acc[i][e];
         __syncthreads();
         if (col_ok) {
-            float f1[8], f2[8], f3[8];
+            // per-tile sums: the fp32 running sums themselves where those are fp32 (64-row variants: registers are scarce there)
+            constexpr bool DIRECT = std::is_same<stat_t, float>::value;
+            float t1[DIRECT ? 1 : 8], t2[DIRECT ? 1 : 8], t3[DIRECT ? 1 : 8];
+            float* const f1 = DIRECT ? reinterpret_cast<float*>(st1) : t1;
+            float* const f2 = DIRECT ? reinterpret_cast<float*>(st2) : t2;
+            float* const f3 = DIRECT ? reinterpret_cast<float*>(st3) : t3;
+            if (!DIRECT)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { f1[j] = 0.f; f2[j] = 0.f; f3[j] = 0.f; }
+                for (int j = 0; j < 8; ++j) { f1[j] = 0.f; f2[j] = 0.f; f3[j] = 0.f; }
+            if (EPI == EPI_DGRAD_POOL) {
+                // a pooled row feeds four source pixels: x of all four, for POOL_CH row groups at a time, is requested before the
+                // first use (16 loads in flight per thread).  One load -> use -> store per trip left 4 KB in flight per workgroup,
+                // i.e. every trip paid a full HBM round trip: 0.5-0.8 TB/s on the wide transitions.  This launch is always the first
+                // contribution to G (g_write, checked by the launcher): G is written, never read.
+                constexpr int POOL_CH = ROWS == 64 ? 2 : 4;       // two workgroups per CU at 64 rows: same bytes in flight per CU
+                const int hw = g.H * g.W;
+#pragma unroll
+                for (int i0 = 0; i0 < ROWS / 16; i0 += POOL_CH) {
+                    u16x8 xv[POOL_CH][4];
+                    long p00[POOL_CH];
+#pragma unroll
+                    for (int c = 0; c < POOL_CH; ++c) {
+                        const long m = mt * ROWS + c_r0 + 16 * (i0 + c);
+                        const long mm = m < g.M ? m : g.M - 1;                          // clamped: the loads stay unconditional
+                        const long img = mm / hw;
+                        const int rem = (int)(mm - img * hw);
+                        const int ho = rem / g.W, wo = rem - ho * g.W;
+                        p00[c] = (img * g.Hin + 2 * ho) * g.Win + 2 * wo;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            xv[c][t] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16*>(g.Xin) + (p00[c] + (t >> 1) * g.Win + (t & 1)) * g.ldxin + ncol);
+                    }
+#pragma unroll
+                    for (int c = 0; c < POOL_CH; ++c) {
+                        const int rr = c_r0 + 16 * (i0 + c);
+                        if (mt * ROWS + rr < g.M) {
+                            const float4 ca = *reinterpret_cast<const float4*>(Cs + rr * CLD + c8 * 8);
+                            const float4 cc = *reinterpret_cast<const float4*>(Cs + rr * CLD + c8 * 8 + 4);
+                            const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cc.x, cc.y, cc.z, cc.w};
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                bf16* gp = reinterpret_cast<bf16*>(g.Gout) + (p00[c] + (t >> 1) * g.Win + (t & 1)) * g.ldgo + ncol;
+                                u16x8 o;
+                                if (ncol + 8 > g.N) o = *reinterpret_cast<const u16x8*>(gp);    // partial last chunk: the rest is not ours
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) {
+                                    const float x = bf2f(xv[c][t][j]);
+                                    const float u = fmaf(x, csc[j], csh[j]);
+                                    const float dA = 0.25f * cv[j];
+                                    const float du = u > 0.f ? dA : csl[j] * dA;
+                                    f1[j] += du; f2[j] += du * x; f3[j] += u > 0.f ? 0.f : dA * u;
+                                    if (ncol + j < g.N) o[j] = f2bf(csc[j] * du);
+                                }
+                                *reinterpret_cast<u16x8*>(gp) = o;
+                            }
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < ROWS / 16; ++i) {
                 const int rr = c_r0 + 16 * i;
@@ -195,47 +251,30 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
                         }
                         *reinterpret_cast<u16x8*>(reinterpret_cast<bf16*>(g.Out) + m * g.ldo + g.n_off + ncol) = o;
                     } else {
-                        const int npx = EPI == EPI_DGRAD_POOL ? 4 : 1;
-                        long p00 = m;
-                        if (EPI == EPI_DGRAD_POOL) {
-                            const int hw = g.H * g.W;
-                            const long img = m / hw;
-                            const int rem = (int)(m - img * hw);
-                            const int ho = rem / g.W, wo = rem - ho * g.W;
-                            p00 = (img * g.Hin + 2 * ho) * g.Win + 2 * wo;
+                        bf16* gp = reinterpret_cast<bf16*>(g.Gout) + m * g.ldgo + ncol;
+                        u16x8 xv, gv;
+                        if (PREF) { xv = pxv[i]; gv = pgv[i]; }
+                        else {
+                            xv = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16*>(g.Xin) + m * g.ldxin + ncol);
+                            gv = *reinterpret_cast<const u16x8*>(gp);
                         }
-#pragma unroll 1
-                        for (int t = 0; t < 4; ++t) {
-                            if (t < npx) {
-                                const long px = EPI == EPI_DGRAD_POOL ? p00 + (t >> 1) * g.Win + (t & 1) : m;
-                                bf16* gp = reinterpret_cast<bf16*>(g.Gout) + px * g.ldgo + ncol;
-                                u16x8 xv, gv;
-                                if (PREF) { xv = pxv[i]; gv = pgv[i]; }
-                                else {
-                                    xv = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16*>(g.Xin) + px * g.ldxin + ncol);
-                                    if (EPI == EPI_DGRAD_POOL && g.g_write) {
+                        u16x8 o;
 #pragma unroll
-                                        for (int j = 0; j < 8; ++j) gv[j] = 0;
-                                    } else gv = *reinterpret_cast<const u16x8*>(gp);
-                                }
-                                u16x8 o;
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) {
-                                    const float x = bf2f(xv[j]);
-                                    const float u = fmaf(x, csc[j], csh[j]);
-                                    const float dA = EPI == EPI_DGRAD_POOL ? 0.25f * cv[j] : cv[j];
-                                    const float du = u > 0.f ? dA : csl[j] * dA;
-                                    f1[j] += du; f2[j] += du * x; f3[j] += u > 0.f ? 0.f : dA * u;
-                                    o[j] = ncol + j < g.N ? f2bf(bf2f(gv[j]) + csc[j] * du) : gv[j];   // beyond N: not ours
-                                }
-                                *reinterpret_cast<u16x8*>(gp) = o;
-                            }
+                        for (int j = 0; j < 8; ++j) {
+                            const float x = bf2f(xv[j]);
+                            const float u = fmaf(x, csc[j], csh[j]);
+                            const float dA = cv[j];
+                            const float du = u > 0.f ? dA : csl[j] * dA;
+                            f1[j] += du; f2[j] += du * x; f3[j] += u > 0.f ? 0.f : dA * u;
+                            o[j] = ncol + j < g.N ? f2bf(bf2f(gv[j]) + csc[j] * du) : gv[j];   // beyond N: not ours
                         }
+                        *reinterpret_cast<u16x8*>(gp) = o;
                     }
                 }
             }
+            if (!DIRECT)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { st1[j] += (stat_t)f1[j]; st2[j] += (stat_t)f2[j]; st3[j] += (stat_t)f3[j]; }
+                for (int j = 0; j < 8; ++j) { st1[j] += (stat_t)f1[j]; st2[j] += (stat_t)f2[j]; st3[j] += (stat_t)f3[j]; }
         }
         __syncthreads();
     }
@@ -278,6 +317,7 @@ bool gemm_nt_ok(const GemmNtArgs& a) {
     if (!a.A || !a.Wfrag || !a.zeros || (a.lda & 7) || (a.K & 7) || a.Kp > nt_max_ksteps(a.epi) * 16 || (a.Kp & 15)) return false;
     if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.Wfrag) & 15)) return false;
     if (a.epi == EPI_FWD) return (a.ldo & 7) == 0 && (a.n_off & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Out) & 15) == 0;
+    if (a.epi == EPI_DGRAD_POOL && !a.g_write) return false;              // the pooled epilogue writes G (first contribution), it never adds
     return (a.ldxin & 7) == 0 && (a.ldgo & 7) == 0 && (reinterpret_cast<uintptr_t>(a.Xin) & 15) == 0 &&
            (reinterpret_cast<uintptr_t>(a.Gout) & 15) == 0;
 }

@@ -197,6 +197,9 @@ __global__ __launch_bounds__(256) void k_pool0_bwd_tile(const Pool0BwdArgs a, in
             o[0] = make_float4(e8[0], e8[1], e8[2], e8[3]); o[1] = make_float4(e8[4], e8[5], e8[6], e8[7]);
         }
         __syncthreads();
+        float f1[8], f2[8], f3[8];                                          // this tile's 8 rows per thread in fp32, folded into fp64 once per tile
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { f1[j] = 0.f; f2[j] = 0.f; f3[j] = 0.f; }
 #pragma unroll 2
         for (int k = 0; k < PB_TH * PB_TW / 32; ++k) {
             const int pi = (tid >> 3) + 32 * k, ly = pi / PB_TW, lx = pi - ly * PB_TW, h = h0 + ly, w = w0 + lx;
@@ -227,11 +230,13 @@ __global__ __launch_bounds__(256) void k_pool0_bwd_tile(const Pool0BwdArgs a, in
                 const float x = xv[j];
                 const float u = fmaf(x, sc[j], sh[j]);
                 const float du = u > 0.f ? z : sl[j] * z;
-                s1[j] += du; s2[j] += (double)du * x; s3[j] += u > 0.f ? 0.f : z * u;
+                f1[j] += du; f2[j] = fmaf(du, x, f2[j]); f3[j] += u > 0.f ? 0.f : z * u;
                 o[j] = sc[j] * du;
             }
             store8_g<T>(DU + p * a.C + c8 * 8, o);
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += (double)f1[j]; s2[j] += (double)f2[j]; s3[j] += (double)f3[j]; }
     }
     // threads with equal (tid & 7) hold the same channels: fold lanes 8, 16, 32 apart, then the four waves
     const int lane = tid & 63, wave = tid >> 6;
