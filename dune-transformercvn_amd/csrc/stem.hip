@@ -159,7 +159,7 @@ template <> __device__ __forceinline__ void store8_g<bf16>(bf16* p, const float 
     *reinterpret_cast<u16x8*>(p) = o;
 }
 template <typename T>
-__global__ __launch_bounds__(256) void k_pool0_bwd_tile(const Pool0BwdArgs a, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, 2) void k_pool0_bwd_tile(const Pool0BwdArgs a, int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) float effs[PB_PH * PB_PW * 64];
     __shared__ double red[4][8][8][3];
     const T* X = reinterpret_cast<const T*>(a.X);
@@ -167,13 +167,16 @@ __global__ __launch_bounds__(256) void k_pool0_bwd_tile(const Pool0BwdArgs a, in
     const T* D = reinterpret_cast<const T*>(a.e.X);
     T* DU = reinterpret_cast<T*>(a.DU);
     const int tid = threadIdx.x, c8 = tid & 7;
-    float sc[8], sh[8], sl[8], cP[8], cQ[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        sc[j] = a.sc[c8 * 8 + j]; sh[j] = a.sh[c8 * 8 + j]; sl[j] = a.sl[c8 * 8 + j];
-        cP[j] = a.e.P[c8 * 8 + j]; cQ[j] = a.e.Q[c8 * 8 + j];
-    }
-    double s1[8], s2[8], s3[8];
+    // per-channel tables live in LDS and are re-read where they are used (a phase needs 16-24 of the 40 values: keeping all of them
+    // and fp64 running sums in registers next to a 2x2 block's 64 operand registers would halve the occupancy)
+    __shared__ __attribute__((aligned(16))) float tabs[5][64];
+    if (tid < 64) { tabs[0][tid] = a.sc[tid]; tabs[1][tid] = a.sh[tid]; tabs[2][tid] = a.sl[tid]; tabs[3][tid] = a.e.P[tid]; tabs[4][tid] = a.e.Q[tid]; }
+    auto tab8 = [&](int which, float (&v)[8]) {
+        const float4 x0 = *reinterpret_cast<const float4*>(&tabs[which][c8 * 8]), x1 = *reinterpret_cast<const float4*>(&tabs[which][c8 * 8 + 4]);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    };
+    // a thread's running sums cover a few hundred values: fp32 here, fp64 across threads and workgroups
+    float s1[8], s2[8], s3[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; s3[j] = 0; }
     const long ntiles = (long)a.n_img * tiles_x * tiles_y;
@@ -187,7 +190,8 @@ __global__ __launch_bounds__(256) void k_pool0_bwd_tile(const Pool0BwdArgs a, in
             float e8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (ho >= 0 && ho < a.Ho && wo >= 0 && wo < a.Wo) {
                 const long mo = (img * a.Ho + ho) * a.Wo + wo;
-                float gv[8], dv[8];
+                float gv[8], dv[8], cP[8], cQ[8];
+                tab8(3, cP); tab8(4, cQ);
                 load8<T>(G + mo * a.e.ldg + c8 * 8, gv);
                 load8<T>(D + mo * a.e.ldx + c8 * 8, dv);
 #pragma unroll
@@ -197,54 +201,57 @@ __global__ __launch_bounds__(256) void k_pool0_bwd_tile(const Pool0BwdArgs a, in
             o[0] = make_float4(e8[0], e8[1], e8[2], e8[3]); o[1] = make_float4(e8[4], e8[5], e8[6], e8[7]);
         }
         __syncthreads();
-        float f1[8], f2[8], f3[8];                                          // this tile's 8 rows per thread in fp32, folded into fp64 once per tile
+        // a thread takes 2x2 blocks of pixels (tile origins are even): the block's four pixels see the pooled windows
+        //   (even,even) all four, (even,odd) the right two, (odd,even) the lower two, (odd,odd) the lower right one
+        // so the four window sums are read once per block (4 LDS reads for 4 pixels instead of 9, no parity branches), and the
+        // block's four x rows are requested together.  Out-of-map windows hold zeros in effs.
+#pragma unroll 1
+        for (int k = 0; k < PB_TH * PB_TW / 128; ++k) {
+            const int bi = (tid >> 3) + 32 * k, by = bi / (PB_TW / 2), bx = bi - by * (PB_TW / 2);
+            const int h = h0 + 2 * by, w = w0 + 2 * bx;
+            float xv[4][8];
+            bool ok[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { f1[j] = 0.f; f2[j] = 0.f; f3[j] = 0.f; }
-#pragma unroll 2
-        for (int k = 0; k < PB_TH * PB_TW / 32; ++k) {
-            const int pi = (tid >> 3) + 32 * k, ly = pi / PB_TW, lx = pi - ly * PB_TW, h = h0 + ly, w = w0 + lx;
-            if (h >= a.Hin || w >= a.Win) continue;
-            // windows containing h: ho = h/2, and h/2 - 1 when h is even (rows 2ho .. 2ho+2); pooled index relative to ho0
-            const int py1 = h / 2 - ho0, px1 = w / 2 - wo0;
-            float dz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = 0; t < 4; ++t) {
+                const int hh = h + (t >> 1), ww = w + (t & 1);
+                ok[t] = (hh < a.Hin) & (ww < a.Win);
+                const long p = ok[t] ? (img * a.Hin + hh) * a.Win + ww : img * a.Hin * a.Win;       // clamped: the load is unconditional
+                load8<T>(X + p * a.C + c8 * 8, xv[t]);
+            }
+            float e[4][8], sc[8], sh[8], sl[8];
+            tab8(0, sc); tab8(1, sh); tab8(2, sl);
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                if (dy == 1 && (h & 1)) continue;
-                const int py = py1 - dy;                                   // out-of-map windows hold zeros in effs
-                if (h / 2 - dy >= a.Ho) continue;
+            for (int t = 0; t < 4; ++t) {
+                const float4* e4 = reinterpret_cast<const float4*>(effs + ((by + (t >> 1)) * PB_PW + bx + (t & 1)) * 64 + c8 * 8);
+                const float4 x0 = e4[0], x1 = e4[1];
+                e[t][0] = x0.x; e[t][1] = x0.y; e[t][2] = x0.z; e[t][3] = x0.w; e[t][4] = x1.x; e[t][5] = x1.y; e[t][6] = x1.z; e[t][7] = x1.w;
+            }
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    if (dx == 1 && (w & 1)) continue;
-                    if (w / 2 - dx >= a.Wo) continue;
-                    const float4* e4 = reinterpret_cast<const float4*>(effs + (py * PB_PW + px1 - dx) * 64 + c8 * 8);
-                    const float4 x0 = e4[0], x1 = e4[1];
-                    dz[0] += x0.x; dz[1] += x0.y; dz[2] += x0.z; dz[3] += x0.w; dz[4] += x1.x; dz[5] += x1.y; dz[6] += x1.z; dz[7] += x1.w;
+            for (int t = 0; t < 4; ++t) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float lower = e[2][j] + e[3][j], right = e[1][j] + e[3][j];
+                    const float dzs = t == 0 ? lower + e[0][j] + e[1][j] : t == 1 ? right : t == 2 ? lower : e[3][j];
+                    const float z = ok[t] ? dzs * (1.0f / 9.0f) : 0.f;
+                    const float x = xv[t][j];
+                    const float u = fmaf(x, sc[j], sh[j]);
+                    const float du = u > 0.f ? z : sl[j] * z;
+                    s1[j] += du; s2[j] = fmaf(du, x, s2[j]); s3[j] += u > 0.f ? 0.f : z * u;
+                    o[j] = sc[j] * du;
                 }
+                if (ok[t]) store8_g<T>(DU + ((img * a.Hin + h + (t >> 1)) * a.Win + w + (t & 1)) * a.C + c8 * 8, o);
             }
-            const long p = (img * a.Hin + h) * a.Win + w;
-            float xv[8], o[8];
-            load8<T>(X + p * a.C + c8 * 8, xv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float z = dz[j] * (1.0f / 9.0f);
-                const float x = xv[j];
-                const float u = fmaf(x, sc[j], sh[j]);
-                const float du = u > 0.f ? z : sl[j] * z;
-                f1[j] += du; f2[j] = fmaf(du, x, f2[j]); f3[j] += u > 0.f ? 0.f : z * u;
-                o[j] = sc[j] * du;
-            }
-            store8_g<T>(DU + p * a.C + c8 * 8, o);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { s1[j] += (double)f1[j]; s2[j] += (double)f2[j]; s3[j] += (double)f3[j]; }
     }
     // threads with equal (tid & 7) hold the same channels: fold lanes 8, 16, 32 apart, then the four waves
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+        double d1 = (double)s1[j], d2 = (double)s2[j], d3 = (double)s3[j];
 #pragma unroll
-        for (int o = 8; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); s3[j] += __shfl_xor(s3[j], o); }
-        if (lane < 8) { red[wave][lane][j][0] = s1[j]; red[wave][lane][j][1] = s2[j]; red[wave][lane][j][2] = s3[j]; }
+        for (int o = 8; o < 64; o <<= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o); }
+        if (lane < 8) { red[wave][lane][j][0] = d1; red[wave][lane][j][1] = d2; red[wave][lane][j][2] = d3; }
     }
     __syncthreads();
     if (tid < 64) {
