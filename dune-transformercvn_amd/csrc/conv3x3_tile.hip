@@ -915,6 +915,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
     if (lb < ntiles) fill_tbl(0, lb);
     __syncthreads();
     if (lb < ntiles) dma_raw(0);
+    // the epilogue's Y rows travel TWO passes ahead of their use, across tile boundaries: pass p of a tile lives in yq[p]; passes
+    // 0/1 of the next tile are requested during passes 2/3 of this one (one pass ahead left a pass shorter than an HBM round trip)
+    u16x8 yq[4][2];
+    if (lb < ntiles) { load_y(0, 0, yq[0]); load_y(0, 1, yq[1]); }
     for (int t = lb; t < ntiles; t += nb, cur ^= 1) {
         if (t + nb < ntiles) fill_tbl(cur ^ 1, t + nb);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of tile t's raw rows has landed
@@ -944,8 +948,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
         }
         __syncthreads();                                         // image complete, raw buffers free again
         if (t + nb < ntiles) dma_raw(cur ^ 1);                   // next tile's slices travel under the MFMAs + epilogue
-        u16x8 ya[2], yb[2];
-        load_y(cur, 0, ya);
 
         // the 128 positions are multiplied in two halves of 64 (two accumulator tiles live instead of four: the kernel sits at
         // the 256-register limit of two workgroups per CU); each half is followed by its two 32-row epilogue passes
@@ -975,9 +977,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             const int pass = half * 2 + pp;
-            u16x8 (&yc)[2] = (pass & 1) ? yb : ya;
-            u16x8 (&yn)[2] = (pass & 1) ? ya : yb;
-            if (pass < 3) load_y(cur, pass + 1, yn);
+            u16x8 (&yc)[2] = yq[pass];
+            if (pass < 2) load_y(cur, pass + 2, yq[pass + 2]);
+            else if (t + nb < ntiles) load_y(cur ^ 1, pass - 2, yq[pass - 2]);      // next tile's table: filled at the top of this iteration
 #pragma unroll
             for (int k = 0; k < 16; ++k) Cs[((k & 3) + 8 * (k >> 2) + 4 * h) * CLD3 + wave * 32 + r] = acc[pp][k];
             lds_barrier();

@@ -185,20 +185,31 @@ __global__ __launch_bounds__(256, 2) void k_pool0_bwd_tile(const Pool0BwdArgs a,
         const long img = tile / ((long)tiles_x * tiles_y);
         const int h0 = ty * PB_TH, w0 = tx * PB_TW, ho0 = h0 / 2 - 1, wo0 = w0 / 2 - 1;
         __syncthreads();                                                   // previous tile's readers are done with effs
-        for (int i = tid; i < PB_PH * PB_PW * 8; i += 256) {               // eff of the pooled pixels (zero outside the map)
-            const int pp = i >> 3, py = pp / PB_PW, px = pp - py * PB_PW, ho = ho0 + py, wo = wo0 + px;
-            float e8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ho >= 0 && ho < a.Ho && wo >= 0 && wo < a.Wo) {
-                const long mo = (img * a.Ho + ho) * a.Wo + wo;
-                float gv[8], dv[8], cP[8], cQ[8];
-                tab8(3, cP); tab8(4, cQ);
-                load8<T>(G + mo * a.e.ldg + c8 * 8, gv);
-                load8<T>(D + mo * a.e.ldx + c8 * 8, dv);
+        {                                                                   // eff of the pooled pixels (zero outside the map)
+            constexpr int NP1 = (PB_PH * PB_PW * 8 + 255) / 256;           // 3 trips: all their loads are requested before the first use
+            float gv[NP1][8], dv[NP1][8];
+            bool in[NP1];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) e8[j] = gv[j] + cP[j] * dv[j] + cQ[j];
+            for (int k = 0; k < NP1; ++k) {
+                const int i = tid + 256 * k, pp = i >> 3, py = pp / PB_PW, px = pp - py * PB_PW, ho = ho0 + py, wo = wo0 + px;
+                in[k] = (i < PB_PH * PB_PW * 8) & (ho >= 0) & (ho < a.Ho) & (wo >= 0) & (wo < a.Wo);
+                const long mo = in[k] ? (img * a.Ho + ho) * a.Wo + wo : img * a.Ho * a.Wo;      // clamped: unconditional loads
+                load8<T>(G + mo * a.e.ldg + c8 * 8, gv[k]);
+                load8<T>(D + mo * a.e.ldx + c8 * 8, dv[k]);
             }
-            float4* o = reinterpret_cast<float4*>(effs + pp * 64 + c8 * 8);
-            o[0] = make_float4(e8[0], e8[1], e8[2], e8[3]); o[1] = make_float4(e8[4], e8[5], e8[6], e8[7]);
+            float cP[8], cQ[8];
+            tab8(3, cP); tab8(4, cQ);
+#pragma unroll
+            for (int k = 0; k < NP1; ++k) {
+                const int i = tid + 256 * k, pp = i >> 3;
+                if (i < PB_PH * PB_PW * 8) {
+                    float e8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e8[j] = in[k] ? gv[k][j] + cP[j] * dv[k][j] + cQ[j] : 0.f;
+                    float4* o = reinterpret_cast<float4*>(effs + pp * 64 + c8 * 8);
+                    o[0] = make_float4(e8[0], e8[1], e8[2], e8[3]); o[1] = make_float4(e8[4], e8[5], e8[6], e8[7]);
+                }
+            }
         }
         __syncthreads();
         // a thread takes 2x2 blocks of pixels (tile origins are even): the block's four pixels see the pooled windows
