@@ -381,6 +381,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
     const bool sparse_stem = !dense_stem_knob && (!train || sparse_train_knob) && L.sidx >= 0 &&
                              stem_sparse_ok(mode, cfg.in_ch, cfg.init_ch, cfg.H, cfg.W, log_pixels, nnz, n, blocks[0].ld);
     last_sparse_stem = sparse_stem;
+    last_fused_ya = false;
     last_values = values; last_value_mode = log_pixels; last_noise = train ? noise_std : 0.f;
     int init_nblk = 0, init_ld = cfg.init_ch;
     if (sparse_stem) {
@@ -441,6 +442,18 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             if ((rc = link(ls.n1, part, new_nblk, new_ld, new_c0, new_n, bstatD, M))) return rc;
             const bool fast1 = L.XA[bi][l] >= 0;
             const int cin8 = (int)round_up(ls.cin, 8);
+            // Eval mode (running statistics: no batch reduction between the 1x1 output and its BatchNorm): the 1x1 GEMM's epilogue
+            // applies norm2 + PReLU and writes the activated map the 3x3 tile kernel stages -- the raw bottleneck output Y and the
+            // k_act_bf16 pass over it (512 B per pixel and layer, one launch) do not exist.  Train mode needs Y for the statistics.
+            bool fuse_ya = false;
+            if (mode == MODE_BF16 && !train && fast1 && xa_materialize()) {
+                ConvFwdArgs c3{};
+                c3.mode = mode; c3.amode = A_3X3; c3.A = ws + L.Y[bi][l]; c3.lda = mid; c3.M = (int)M; c3.N = g; c3.K = 9 * mid;
+                c3.Kp = wk_find(ls.w2, 0).Kp; c3.C = mid; c3.H = bg.H; c3.W = bg.W; c3.Wk = ws + L.wk + wk_find(ls.w2, 0).off;
+                c3.Wfrag = wk_frag(ws, L, ls.w2, 0); c3.Aact = ws + L.YA[bi][l]; c3.zeros = ws + L.zeros;
+                fuse_ya = conv3x3_tile_ok(c3);
+            }
+            if (fuse_ya) last_fused_ya = true;
             if (fast1 && xa_materialize()) {     // activated copy of the 1x1 input: operand of the bf16 GEMMs (forward, weight gradient)
                 Tab t1 = tab(ls.n1);
                 ActArgs act{D, bg.ld, M, ls.cin, t1.sc, t1.sh, data[ls.a1], ws + L.XA[bi][l], cin8};
@@ -456,6 +469,10 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 }
                 a.Wfrag = ws + L.wk + e.off; a.Kp = e.Kp; a.zeros = ws + L.zeros; a.bias = data[ls.b1];
                 a.Out = ws + L.Y[bi][l]; a.ldo = mid; a.n_off = 0; a.part = train ? part : nullptr; a.nblk = gemm_nt_nblk(a);
+                if (fuse_ya) {                 // eval: norm2 + PReLU in the GEMM epilogue, the activated map is the only output
+                    Tab t2 = tab(ls.n2);
+                    a.osc = t2.sc; a.osh = t2.sh; a.osl = data[ls.a2]; a.Out = ws + L.YA[bi][l];
+                }
                 if ((rc = gemm_nt_bf16(a, "k_gemm_nt_bf16<fwd1x1>", st))) return rc;
                 if ((rc = link(ls.n2, part, a.nblk, mid, 0, mid, reinterpret_cast<double*>(ws + L.bstatY[bi][l]), M))) return rc;
             } else {   // bottleneck 1x1: D[:, 0:cin] -> Y
@@ -478,8 +495,10 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 a.Wk = ws + L.wk + e.off; a.bias = data[ls.b2]; a.Out = D; a.ldo = bg.ld; a.n_off = ls.cin;
                 a.Wfrag = wk_frag(ws, L, ls.w2, 0);
                 if (mode == MODE_BF16) {       // materialise prelu(bn(Y)) once; the tile kernel stages it by LDS-DMA
-                    ActArgs act{ws + L.Y[bi][l], mid, M, mid, t.sc, t.sh, data[ls.a2], ws + L.YA[bi][l], mid};
-                    if ((rc = act_bf16(act, st))) return rc;
+                    if (!fuse_ya) {
+                        ActArgs act{ws + L.Y[bi][l], mid, M, mid, t.sc, t.sh, data[ls.a2], ws + L.YA[bi][l], mid};
+                        if ((rc = act_bf16(act, st))) return rc;
+                    }
                     a.Aact = ws + L.YA[bi][l]; a.zeros = ws + L.zeros;
                 }
                 a.part = train ? part : nullptr;
@@ -567,6 +586,7 @@ int DenseNetPlan::tap(int n, const char* name, long* off, int* tn, int* th, int*
         if (sscanf(s.c_str(), "bottleneck%d.%d", &b, &l) != 2) return -1;
         b -= 1;
         if (b < 0 || b >= (int)blocks.size() || l < 0 || l >= blocks[b].L) return -1;
+        if (last_fused_ya && n == last_n) return -1;             // eval pass with the activation in the GEMM epilogue: no raw Y exists
         *off = L.Y[b][l]; *th = blocks[b].H; *tw = blocks[b].W; *tc = cfg.bn_size * cfg.growth; *tld = *tc;
         return 0;
     }

@@ -55,6 +55,7 @@ struct DenseNetPlan {
     uint64_t last_seed = 0; int last_n = 0;
     const int32_t* last_coords = nullptr; long last_nnz = 0;     // COO list of the last forward (sparse stem weight gradient)
     const float* last_values = nullptr; int last_value_mode = 0; float last_noise = 0.f;
+    bool last_fused_ya = false;          // the last forward was an eval pass whose 1x1 GEMMs wrote the activated bottleneck maps only (no raw Y)
     bool last_sparse_stem = false;       // the last forward ran the sparse-aware stem: no dense map / conv0 output exists (backward must match)
     bool sparse_stem_possible() const;   // plan-level condition (bf16, 3 -> 64 channels); the hit count decides per call
     // weight-gradient side stream of backward (3x3 and 1x1 weight gradients run beside the data-gradient chain)

@@ -14,7 +14,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_link(const BnBwdLinkArgs a) {
     const int c = blockIdx.x * 4 + wave;
     if (c >= a.C) return;
     double s1 = 0, t2 = 0, s3 = 0;
-    for (int b = lane; b < a.nblk; b += 64) {
+    int b = lane;
+    for (; b + 192 < a.nblk; b += 256) {                        // four partial rows per trip: twelve loads in flight per lane (the fp32
+        const double* p0 = a.part + ((long)b * a.C + c) * 3;    // tile kernels leave thousands of rows; one row per trip is a chain
+        const double* p1 = p0 + (long)64 * a.C * 3;             // of L2 round trips)
+        const double* p2 = p0 + (long)128 * a.C * 3;
+        const double* p3 = p0 + (long)192 * a.C * 3;
+        const double a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+        const double c0 = p2[0], c1 = p2[1], c2 = p2[2], d0 = p3[0], d1 = p3[1], d2 = p3[2];
+        s1 += (a0 + b0) + (c0 + d0); t2 += (a1 + b1) + (c1 + d1); s3 += (a2 + b2) + (c2 + d2);
+    }
+    for (; b < a.nblk; b += 64) {
         const double* p = a.part + ((long)b * a.C + c) * 3;
         s1 += p[0]; t2 += p[1]; s3 += p[2];
     }

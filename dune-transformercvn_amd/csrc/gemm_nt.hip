@@ -38,6 +38,9 @@ __device__ __forceinline__ void dma_a(char* smem_base, int buf_off, const bf16* 
 
 // XF = 1 (forward only): A is the RAW BatchNorm input; every landed A tile is transformed in LDS to prelu(sc*x + sh) before the
 // MFMAs read it (tables in LDS, 4-8 16-B chunks per thread), so the activated copy of the concat buffer is never written to HBM
+// XF = 2 (forward, eval mode): the epilogue applies the NEXT BatchNorm (running statistics: no batch reduction to wait for) and
+// PReLU to the fp32 result before the one rounding to bf16 -- the raw 1x1 output and the pass that activated it disappear;
+// no statistics in this instance
 template <int EPI, int MAXKS, int ROWS, int XF = 0>
 __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const GemmNtArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -75,9 +78,13 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
     for (int j = 0; j < 8; ++j) {
         const bool ok = ncol + j < g.N;
         cb[j] = (EPI == EPI_FWD && ok) ? g.bias[ncol + j] : 0.f;
-        csc[j] = (EPI != EPI_FWD && ok) ? g.sc[ncol + j] : 0.f;
-        csh[j] = (EPI != EPI_FWD && ok) ? g.sh[ncol + j] : 0.f;
-        csl[j] = (EPI != EPI_FWD && ok) ? g.sl[ncol + j] : 0.f;
+        if (XF == 2) {
+            csc[j] = ok ? g.osc[ncol + j] : 0.f; csh[j] = ok ? g.osh[ncol + j] : 0.f; csl[j] = ok ? g.osl[ncol + j] : 0.f;
+        } else {
+            csc[j] = (EPI != EPI_FWD && ok) ? g.sc[ncol + j] : 0.f;
+            csh[j] = (EPI != EPI_FWD && ok) ? g.sh[ncol + j] : 0.f;
+            csl[j] = (EPI != EPI_FWD && ok) ? g.sl[ncol + j] : 0.f;
+        }
     }
     // per-thread running sums: a thread sees at most a few hundred rows per channel, so the two-blocks-per-CU variants keep
     // them in fp32 (registers); everything across threads and workgroups is reduced in fp64
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { st1[j] = 0; st2[j] = 0; st3[j] = 0; }
 
-    if (XF) {
+    if (XF == 1) {
         for (int i = threadIdx.x; i < Kt; i += 256) {
             const bool ok = i < g.Kreal;
             atab[i] = ok ? g.asc[i] : 0.f; atab[Kt + i] = ok ? g.ash[i] : 0.f; atab[2 * Kt + i] = ok ? g.asl[i] : 0.f;
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
                 if (kc + 1 < nkc) dma_a<ROWS>(smem, (cur ^ 1) * TILE, A, g.lda, g.K, (kc + 1) * 128, mt * ROWS, g.M, zeros, wave, lane);
                 else if (mt + gridDim.x < mtiles) dma_a<ROWS>(smem, (cur ^ 1) * TILE, A, g.lda, g.K, 0, (mt + gridDim.x) * ROWS, g.M, zeros, wave, lane);
                 const int ab = cur * TILE;
-                if (XF) {                       // bare barrier: a __syncthreads() would drain the prefetch just issued
+                if (XF == 1) {                  // bare barrier: a __syncthreads() would drain the prefetch just issued
                     xform(ab, kc);
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 }
@@ -245,9 +252,10 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
                         u16x8 o;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            o[j] = ncol + j < g.N ? f2bf(cv[j] + cb[j]) : (bf16)0;     // channels beyond N: zero (written later)
-                            const float x = bf2f(o[j]);
-                            f1[j] += x; f2[j] += x * x;
+                            float v = cv[j] + cb[j];
+                            if (XF == 2) v = prelu(fmaf(v, csc[j], csh[j]), csl[j]);
+                            o[j] = ncol + j < g.N ? f2bf(v) : (bf16)0;                   // channels beyond N: zero (written later)
+                            if (XF != 2) { const float x = bf2f(o[j]); f1[j] += x; f2[j] += x * x; }
                         }
                         *reinterpret_cast<u16x8*>(reinterpret_cast<bf16*>(g.Out) + m * g.ldo + g.n_off + ncol) = o;
                     } else {
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
         }
         __syncthreads();
     }
-    if (g.part == nullptr) return;
+    if (XF == 2 || g.part == nullptr) return;
     // reduce over the 16 row groups: 4 per wave by shuffles (lanes differing in bits 4,5), then across waves through LDS
     constexpr int NS = EPI == EPI_FWD ? 2 : 3;
 #pragma unroll
@@ -369,7 +377,8 @@ int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
     const size_t smem = 2 * rows * 256 + (size_t)rows * CLD * 4 + (a.epi == EPI_FWD && a.asc != nullptr ? 3 * ((a.K + 7) & ~7) * 4 : 0);
     static bool attr = false;
     if (!attr) {
-        const void* fns[8] = {reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128>),
+        const void* fns[10] = {reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128, 2>),
+                              reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64, 2>),reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128>),
                               reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64>),
                               reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD, 64>),
                               reinterpret_cast<const void*>(k_gemm_nt_bf16<EPI_DGRAD, KS_DGRAD_SMALL, 64>),
@@ -388,7 +397,11 @@ int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st) {
     ProfScope ps(label, 2.0 * a.M * (double)a.N * a.K, bytes, st);
     const dim3 grid(gemm_nt_nblk(a), cdiv(a.N, 128));
     const bool xf = a.epi == EPI_FWD && a.asc != nullptr;
-    if (xf && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64, 1>), grid, dim3(256), smem, st, a);
+    const bool oact = a.epi == EPI_FWD && a.osc != nullptr;
+    if (oact && (xf || a.part != nullptr || !a.osh || !a.osl)) return -2;      // eval-mode epilogue: no statistics, materialised A
+    if (oact && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64, 2>), grid, dim3(256), smem, st, a);
+    else if (oact) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128, 2>), grid, dim3(256), smem, st, a);
+    else if (xf && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64, 1>), grid, dim3(256), smem, st, a);
     else if (xf) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128, 1>), grid, dim3(256), smem, st, a);
     else if (a.epi == EPI_FWD && a.Kp <= KS_FWD_SMALL * 16) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD_SMALL, 64>), grid, dim3(256), smem, st, a);
     else if (a.epi == EPI_FWD) hipLaunchKernelGGL((k_gemm_nt_bf16<EPI_FWD, KS_FWD, 128>), grid, dim3(256), smem, st, a);

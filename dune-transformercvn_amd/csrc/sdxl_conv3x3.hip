@@ -29,7 +29,6 @@ constexpr int PS = 144;                               // bytes per patch pixel (
 constexpr int PATCH_BYTES = ((PH * PW + 6) / 7) * 7 * PS;    // 49 392: whole LDS-DMA groups of 7 pixels
 constexpr int CP = 68;                                // fp32 C tile pitch (floats)
 constexpr int CT_BYTES = 128 * CP * 4;                // 34 816
-constexpr int NCHUNK = PH * PW * 8;                   // 16-B chunks of a patch (2 720)
 
 // Tile -> pixel mapping of the 8 x 32 stride-1 tile.  Large maps: tiles_x x tiles_y tiles per image.  Small maps would waste most
 // of a tile (a 7 x 5 map fills 14 % of it) and re-read the weights once per image, so maps of width <= 15 are PACKED side by side

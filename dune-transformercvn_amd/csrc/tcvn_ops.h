@@ -210,6 +210,8 @@ struct GemmNtArgs {
     const float* bias; void* Out; long ldo; int n_off;             // EPI_FWD
     const float *asc, *ash, *asl; int Kreal;                       // EPI_FWD, optional: A is raw, transform prelu(asc*x + ash, asl) in LDS;
                                                                    // channels >= Kreal are zeroed
+    const float *osc, *osh, *osl;                                  // EPI_FWD, optional (eval mode, part == nullptr): Out = prelu(osc*(C + bias) + osh, osl)
+                                                                   // -- the consumer's BatchNorm (running statistics) + PReLU applied in the epilogue
     const void* Xin; long ldxin; const float *sc, *sh, *sl;        // EPI_DGRAD*: BatchNorm input + its table
     void* Gout; long ldgo;
     int g_write;                             // EPI_DGRAD_POOL: this launch is the FIRST contribution to Gout: write, do not read-add
