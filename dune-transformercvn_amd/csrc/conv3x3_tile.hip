@@ -315,6 +315,7 @@ size_t fwd_ring_smem() { return RING * 256 + RING * 4 + 4 * 32 * 16; }
 // phase counters of the pair kernel (validation build only): wave-cycles per phase, reported by every 16th workgroup
 #ifdef TCVN_DEBUG_KNOBS
 __device__ unsigned long long g_pair_ph[16];
+__device__ unsigned long long g_wg_ph[16];                   // the same for k_conv3x3_wgrad_bf16
 #define PAIR_T0() unsigned long long ph_t = clock64()
 #define PAIR_PH(i) do { const unsigned long long n_ = clock64(); ph[i] += n_ - ph_t; ph_t = n_; } while (0)
 #else
@@ -646,6 +647,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
     const int b_colbyte = (16 * chalf + 4 * tp) * 2;                                  // eff: 32 channels
 
     int cur = 0, ts = 0;
+#ifdef TCVN_DEBUG_KNOBS
+    unsigned long long ph[16] = {0};
+#endif
+    PAIR_T0();
     for (int t = lb; t < ntiles; t += nb, cur ^= 1, ts = ts == 2 ? 0 : ts + 1) {
         const int tn = ts == 2 ? 0 : ts + 1, tnn = tn == 2 ? 0 : tn + 1;
         const bool more = t + nb < ntiles;
@@ -653,9 +658,11 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         int mm[2] = {-1, -1};
         if (more) {
             dma_image(smem, (cur ^ 1) * img_bytes, YA, zeros, tbl + tn * nrows4, nrows4, wave, lane);
+            PAIR_PH(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i) mm[i] = eff_load(tbl + tn * nrows4, i, gv[i], xv[i]);
         }
+        PAIR_PH(1);
         const int image = cur * img_bytes, effb = eff_off + cur * TP * 64;
 #pragma unroll 2
         for (int ks = 0; ks < TP / 16; ++ks) {
@@ -670,14 +677,24 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
             }
         }
+        PAIR_PH(2);
         if (more) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) eff_store(cur ^ 1, i, mm[i], gv[i], xv[i]);
         }
+        PAIR_PH(3);
         if (t + 2 * nb < ntiles) fill_tbl(tnn, t + 2 * nb);
+        PAIR_PH(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PAIR_PH(5);
         __syncthreads();
+        PAIR_PH(6);
     }
+#ifdef TCVN_DEBUG_KNOBS
+    if (lane == 0 && (blockIdx.x & 15) == 0)
+        for (int i = 0; i < 16; ++i)
+            if (ph[i]) atomicAdd(&g_wg_ph[i], ph[i]);
+#endif
 
     // dW[tap*128 + c][n] += acc ; rows of the C tile are this wave's channels, columns the 32 output channels
     const int n = lane & 31, hh = lane >> 5;
@@ -1212,5 +1229,10 @@ extern "C" void tcvn_debug_pair_phases(unsigned long long* out16, int reset) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(tcvn::g_pair_ph), 16 * 8);
     if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(tcvn::g_pair_ph), z, 16 * 8); }
+}
+extern "C" void tcvn_debug_wgrad_phases(unsigned long long* out16, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(tcvn::g_wg_ph), 16 * 8);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(tcvn::g_wg_ph), z, 16 * 8); }
 }
 #endif
