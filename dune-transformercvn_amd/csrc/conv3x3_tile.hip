@@ -40,13 +40,25 @@ __device__ __forceinline__ int pix_of(const PadGeom& q, int g, float invWp, floa
 __device__ __forceinline__ void dma_image(char* smem_base, int buf_off, const bf16* __restrict__ XA, const char* __restrict__ zeros,
                                           const int* rowpix, int nrows4, int wave, int lane) {
     const int rsub = lane >> 4, slot = lane & 15;
-    for (int rg = wave; rg * 4 < nrows4; rg += 4) {
-        const int r = rg * 4 + rsub;
-        const int m = rowpix[r];                       // pixel index of this image row or -1 (table filled a tile ahead)
-        const char* src = m >= 0 ? reinterpret_cast<const char*>(XA + (long)m * 128) + ((slot ^ (r & 15)) << 4)
-                                 : zeros + (slot << 4);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(smem_base + buf_off + rg * 1024), 16, 0, 0);
+    // all table entries first, then all DMA instructions: one table read per DMA was an exposed LDS round trip each (4 500 of the weight
+    // gradient's 17 400 cycles per wave and tile in the phase counters).  Up to DMA_RG row groups per wave = 384 image rows.
+    constexpr int DMA_RG = 24;
+    int mrow[DMA_RG];
+#pragma unroll
+    for (int i = 0; i < DMA_RG; ++i) {
+        const int rg = wave + 4 * i;
+        mrow[i] = rg * 4 < nrows4 ? rowpix[rg * 4 + rsub] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < DMA_RG; ++i) {
+        const int rg = wave + 4 * i, r = rg * 4 + rsub;
+        if (rg * 4 < nrows4) {
+            const int m = mrow[i];                     // pixel index of this image row or -1 (table filled a tile ahead)
+            const char* src = m >= 0 ? reinterpret_cast<const char*>(XA + (long)m * 128) + ((slot ^ (r & 15)) << 4)
+                                     : zeros + (slot << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem_base + buf_off + rg * 1024), 16, 0, 0);
+        }
     }
 }
 
@@ -646,6 +658,15 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
     const int a_chunk = wave * 4 + 2 * chalf + (tp >> 1), a_sub = (tp & 1) * 8;       // Yact: this wave's 32 channels
     const int b_colbyte = (16 * chalf + 4 * tp) * 2;                                  // eff: 32 channels
 
+    // image offsets of this lane's two transposed reads per tap at k-step 0 (rows arow and arow + 4 of the padded tile)
+    int a_lo[9], a_hi[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int arow = q.halo + (tap / 3 - 1) * q.Wp + (tap % 3 - 1) + 8 * khalf + tq, r2 = arow + 4;
+        a_lo[tap] = arow * 256 + ((a_chunk ^ (arow & 15)) << 4) + a_sub;
+        a_hi[tap] = r2 * 256 + ((a_chunk ^ (r2 & 15)) << 4) + a_sub;
+    }
+    const int b_off0 = (8 * khalf + tq) * 64 + b_colbyte;
     int cur = 0, ts = 0;
 #ifdef TCVN_DEBUG_KNOBS
     unsigned long long ph[16] = {0};
@@ -664,17 +685,42 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         }
         PAIR_PH(1);
         const int image = cur * img_bytes, effb = eff_off + cur * TP * 64;
-#pragma unroll 2
-        for (int ks = 0; ks < TP / 16; ++ks) {
-            const int brow = ks * 16 + 8 * khalf + tq;
-            const bf16x8_t b = tr_frag(smem, effb + brow * 64 + b_colbyte, effb + (brow + 4) * 64 + b_colbyte);
+        // 8 k-steps x (1 eff + 9 image fragments, two transposed LDS reads each) as a software pipeline over 24 groups of three image
+        // fragments (the first group of a k-step also carries the eff fragment): group j+2 is requested while group j is multiplied, so
+        // 12-14 LDS reads stay in flight (lgkmcnt holds 15) instead of every k-step waiting for its own 20 reads (7 200 cycles per wave and
+        // tile in the phase counters against 2 300 of MFMA issue).  The waits are placed by hand in front of the new requests -- left to
+        // itself the compiler sinks the requests behind the MFMAs or waits for all of them.
+        {
+            bf16x8_t fa[3][3], fb[2];
+            // k-step ks reads 16 rows further down: + ks * 4096 B in the image (row & 15, hence the swizzle, is unchanged) and
+            // + ks * 1024 B in the eff tile -- immediates of the read instructions; 18 + 1 address registers serve all 160 reads
+            const char* ibase = smem + image;
+            const char* ebase = smem + effb + b_off0;
+            auto issue = [&](int j) {                                          // j = 3 * ks + third
+                const int ks = j / 3, third = j - 3 * ks;
+                if (third == 0) fb[ks & 1] = tr_frag(ebase, ks * 1024, ks * 1024 + 256);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int arow = q.halo + (tap / 3 - 1) * q.Wp + (tap % 3 - 1) + brow;
-                const int r2 = arow + 4;
-                const bf16x8_t a = tr_frag(smem, image + arow * 256 + ((a_chunk ^ (arow & 15)) << 4) + a_sub,
-                                           image + r2 * 256 + ((a_chunk ^ (r2 & 15)) << 4) + a_sub);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
+                for (int i = 0; i < 3; ++i) {
+                    const int tap = third * 3 + i;
+                    fa[j % 3][i] = tr_frag(ibase, a_lo[tap] + ks * 4096, a_hi[tap] + ks * 4096);
+                }
+            };
+            constexpr int NG = 3 * (TP / 16);
+            issue(0);
+            issue(1);
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                // group j complete <=> at most the reads of group j+1 outstanding (6, or 8 when it opens a k-step)
+                if (j + 1 < NG) { if ((j + 1) % 3 == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (8 << 8)); else __builtin_amdgcn_s_waitcnt(0xC07F | (6 << 8)); }
+                else __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 2 < NG) issue(j + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                const int ks = j / 3, third = j - 3 * ks;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    acc[third * 3 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j % 3][i], fb[ks & 1], acc[third * 3 + i], 0, 0, 0);
             }
         }
         PAIR_PH(2);
