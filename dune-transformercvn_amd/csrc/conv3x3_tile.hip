@@ -579,7 +579,14 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* smem_base, int off_lo, i
     return __builtin_bit_cast(bf16x8_t, pr);
 }
 
-__global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradArgs g, int n_img, int ntiles, int swz) {
+// Two waves per SIMD with different roles (as in the forward pair kernel): 512 threads.  Waves 0-3 only multiply -- the pipelined
+// fragment reads + 72 MFMAs of tile t.  Waves 4-7 prepare tile t+1 meanwhile: image DMA (whose issue stalls while the memory pipe is
+// full: 4 900 cycles per tile in the phase counters, with nothing left to wait for afterwards), the eff tile (slice loads, BatchNorm
+// mean terms, dropout hash: 3 700), the pixel table of tile t+2 (1 100).  One barrier per tile.  The one-role kernel ran those 9 700
+// cycles and the 5 300 of the k loop one after the other in every wave.  The roles are separate code paths (separate live ranges:
+// 144 accumulators + fragments on one side, tables and hash state on the other; a merged body needs more than the 256 registers
+// two waves per SIMD leave each).
+__global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradArgs g, int n_img, int ntiles, int swz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvFwdArgs& fa = g.fa;
     const EffSrc& e = g.e;
@@ -591,118 +598,133 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
     float* bred = reinterpret_cast<float*>(smem + eff_off);        // [64][32], aliases the eff images after the last barrier
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
-    const bf16* __restrict__ YA = reinterpret_cast<const bf16*>(fa.Aact);
-    const char* __restrict__ zeros = reinterpret_cast<const char*>(fa.zeros);
-    const bf16* __restrict__ G = reinterpret_cast<const bf16*>(e.G);
-    const bf16* __restrict__ D = reinterpret_cast<const bf16*>(e.X);
+    const int w4 = wave & 3, htid = tid & 255;                             // wave / thread index inside the role
     const int nb = gridDim.x;
     const int lb = swz ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const bool drop = e.drop_p > 0.f;
-    const uint32_t dkey = drop_key(e.seed, e.stream_id);
-
-    // eff staging: thread -> (rows ra = tid>>2 and ra+64, channel chunk ec = tid&3)
-    const int ec = tid & 3, ra = tid >> 2;
-    float cP[8], cQ[8], bsum[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int n = ec * 8 + j;
-        cP[j] = n < e.N ? e.P[n] : 0.f; cQ[j] = n < e.N ? e.Q[n] : 0.f; bsum[j] = 0.f;
-    }
-    auto eff_load = [&](const int* rowpix, int i, u16x8& gv, u16x8& xv) -> int {
-        const int m = rowpix[q.halo + ra + 64 * i];
-        const long o = (long)(m >= 0 ? m : 0);
-        gv = *reinterpret_cast<const u16x8*>(G + o * e.ldg + e.c_off + ec * 8);
-        xv = *reinterpret_cast<const u16x8*>(D + o * e.ldx + e.c_off + ec * 8);
-        return m;
-    };
-    auto eff_store = [&](int buf, int i, int m, const u16x8& gv, const u16x8& xv) {
-        u16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float t = 0.f;
-            const int n = ec * 8 + j;
-            if (m >= 0 && n < e.N) {
-                t = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
-                if (drop) t *= drop_pick(drop_bits32(dkey, m, n, e.N), m, e.drop_p);      // (pixels * N < 2^32: conv3x3_wgrad_tile_ok)
-            }
-            o[j] = f2bf(t);
-            bsum[j] += bf2f(o[j]);
-        }
-        *reinterpret_cast<u16x8*>(smem + eff_off + buf * TP * 64 + (ra + 64 * i) * 64 + ec * 16) = o;
-    };
-    auto fill_tbl = [&](int slot, int tile) {
-        for (int rr = tid; rr < nrows4; rr += 256) tbl[slot * nrows4 + rr] = pix_of(q, tile * TP - q.halo + rr, invWp, invHp);
-    };
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-    if (lb < ntiles) fill_tbl(0, lb);
-    if (lb + nb < ntiles) fill_tbl(1, lb + nb);
-    __syncthreads();
-    if (lb < ntiles) {
-        dma_image(smem, 0, YA, zeros, tbl, nrows4, wave, lane);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { u16x8 gv, xv; const int m = eff_load(tbl, i, gv, xv); eff_store(0, i, m, gv, xv); }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // tr-read lane roles: group gq = lane>>4 -> (k half = gq>>1, column half = gq&1); lane 4q+p supplies row q, cols 4p..4p+3
-    const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-    const int khalf = gq >> 1, chalf = gq & 1;
-    const int a_chunk = wave * 4 + 2 * chalf + (tp >> 1), a_sub = (tp & 1) * 8;       // Yact: this wave's 32 channels
-    const int b_colbyte = (16 * chalf + 4 * tp) * 2;                                  // eff: 32 channels
-
-    // image offsets of this lane's two transposed reads per tap at k-step 0 (rows arow and arow + 4 of the padded tile)
-    int a_lo[9], a_hi[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int arow = q.halo + (tap / 3 - 1) * q.Wp + (tap % 3 - 1) + 8 * khalf + tq, r2 = arow + 4;
-        a_lo[tap] = arow * 256 + ((a_chunk ^ (arow & 15)) << 4) + a_sub;
-        a_hi[tap] = r2 * 256 + ((a_chunk ^ (r2 & 15)) << 4) + a_sub;
-    }
-    const int b_off0 = (8 * khalf + tq) * 64 + b_colbyte;
-    int cur = 0, ts = 0;
 #ifdef TCVN_DEBUG_KNOBS
     unsigned long long ph[16] = {0};
 #endif
-    PAIR_T0();
-    for (int t = lb; t < ntiles; t += nb, cur ^= 1, ts = ts == 2 ? 0 : ts + 1) {
-        const int tn = ts == 2 ? 0 : ts + 1, tnn = tn == 2 ? 0 : tn + 1;
-        const bool more = t + nb < ntiles;
-        u16x8 gv[2], xv[2];
-        int mm[2] = {-1, -1};
-        if (more) {
-            dma_image(smem, (cur ^ 1) * img_bytes, YA, zeros, tbl + tn * nrows4, nrows4, wave, lane);
-            PAIR_PH(0);
+
+    if (wave >= 4) {
+        // ---------------- helper role: tables, image DMA, eff tiles ----------------
+        const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
+        const bf16* __restrict__ YA = reinterpret_cast<const bf16*>(fa.Aact);
+        const char* __restrict__ zeros = reinterpret_cast<const char*>(fa.zeros);
+        const bf16* __restrict__ G = reinterpret_cast<const bf16*>(e.G);
+        const bf16* __restrict__ D = reinterpret_cast<const bf16*>(e.X);
+        const bool drop = e.drop_p > 0.f;
+        const uint32_t dkey = drop_key(e.seed, e.stream_id);
+        const int ec = htid & 3, ra = htid >> 2;                           // eff staging: rows ra and ra + 64, channel chunk ec
+        float cP[8], cQ[8], bsum[8];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) mm[i] = eff_load(tbl + tn * nrows4, i, gv[i], xv[i]);
+        for (int j = 0; j < 8; ++j) {
+            const int n = ec * 8 + j;
+            cP[j] = n < e.N ? e.P[n] : 0.f; cQ[j] = n < e.N ? e.Q[n] : 0.f; bsum[j] = 0.f;
         }
-        PAIR_PH(1);
-        const int image = cur * img_bytes, effb = eff_off + cur * TP * 64;
-        // 8 k-steps x (1 eff + 9 image fragments, two transposed LDS reads each) as a software pipeline over 24 groups of three image
-        // fragments (the first group of a k-step also carries the eff fragment): group j+2 is requested while group j is multiplied, so
-        // 12-14 LDS reads stay in flight (lgkmcnt holds 15) instead of every k-step waiting for its own 20 reads (7 200 cycles per wave and
-        // tile in the phase counters against 2 300 of MFMA issue).  The waits are placed by hand in front of the new requests -- left to
-        // itself the compiler sinks the requests behind the MFMAs or waits for all of them.
-        {
-            bf16x8_t fa[3][3], fb[2];
+        auto eff_load = [&](const int* rowpix, int i, u16x8& gv, u16x8& xv) -> int {
+            const int m = rowpix[q.halo + ra + 64 * i];
+            const long o = (long)(m >= 0 ? m : 0);
+            gv = *reinterpret_cast<const u16x8*>(G + o * e.ldg + e.c_off + ec * 8);
+            xv = *reinterpret_cast<const u16x8*>(D + o * e.ldx + e.c_off + ec * 8);
+            return m;
+        };
+        auto eff_store = [&](int buf, int i, int m, const u16x8& gv, const u16x8& xv) {
+            u16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = 0.f;
+                const int n = ec * 8 + j;
+                if (m >= 0 && n < e.N) {
+                    t = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
+                    if (drop) t *= drop_pick(drop_bits32(dkey, m, n, e.N), m, e.drop_p);      // (pixels * N < 2^32: conv3x3_wgrad_tile_ok)
+                }
+                o[j] = f2bf(t);
+                bsum[j] += bf2f(o[j]);
+            }
+            *reinterpret_cast<u16x8*>(smem + eff_off + buf * TP * 64 + (ra + 64 * i) * 64 + ec * 16) = o;
+        };
+        auto fill_tbl = [&](int slot, int tile) {
+            for (int rr = htid; rr < nrows4; rr += 256) tbl[slot * nrows4 + rr] = pix_of(q, tile * TP - q.halo + rr, invWp, invHp);
+        };
+        if (lb < ntiles) fill_tbl(0, lb);
+        if (lb + nb < ntiles) fill_tbl(1, lb + nb);
+        __syncthreads();                                                    // (1)
+        if (lb < ntiles) {
+            dma_image(smem, 0, YA, zeros, tbl, nrows4, w4, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { u16x8 gv, xv; const int m = eff_load(tbl, i, gv, xv); eff_store(0, i, m, gv, xv); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                    // (2)
+        int cur = 0, ts = 0;
+        PAIR_T0();
+        for (int t = lb; t < ntiles; t += nb, cur ^= 1, ts = ts == 2 ? 0 : ts + 1) {
+            const int tn = ts == 2 ? 0 : ts + 1, tnn = tn == 2 ? 0 : tn + 1;
+            if (t + nb < ntiles) {
+                dma_image(smem, (cur ^ 1) * img_bytes, YA, zeros, tbl + tn * nrows4, nrows4, w4, lane);
+                PAIR_PH(8);
+                u16x8 gv[2], xv[2];
+                int mm[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) mm[i] = eff_load(tbl + tn * nrows4, i, gv[i], xv[i]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) eff_store(cur ^ 1, i, mm[i], gv[i], xv[i]);
+                PAIR_PH(9);
+            }
+            if (t + 2 * nb < ntiles) fill_tbl(tnn, t + 2 * nb);
+            PAIR_PH(10);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PAIR_PH(11);
+            __syncthreads();                                                // (tile)
+            PAIR_PH(12);
+        }
+        if (g.dbias != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bred[ra * 32 + ec * 8 + j] = bsum[j];
+        }
+    } else {
+        // ---------------- multiplying role ----------------
+        f32x16 acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        // tr-read lane roles: group gq = lane>>4 -> (k half = gq>>1, column half = gq&1); lane 4q+p supplies row q, cols 4p..4p+3
+        const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+        const int khalf = gq >> 1, chalf = gq & 1;
+        const int a_chunk = w4 * 4 + 2 * chalf + (tp >> 1), a_sub = (tp & 1) * 8;         // Yact: this wave's 32 channels
+        const int b_colbyte = (16 * chalf + 4 * tp) * 2;                                  // eff: 32 channels
+        // image offsets of this lane's two transposed reads per tap at k-step 0 (rows arow and arow + 4 of the padded tile)
+        int a_lo[9], a_hi[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int arow = q.halo + (tap / 3 - 1) * q.Wp + (tap % 3 - 1) + 8 * khalf + tq, r2 = arow + 4;
+            a_lo[tap] = arow * 256 + ((a_chunk ^ (arow & 15)) << 4) + a_sub;
+            a_hi[tap] = r2 * 256 + ((a_chunk ^ (r2 & 15)) << 4) + a_sub;
+        }
+        const int b_off0 = (8 * khalf + tq) * 64 + b_colbyte;
+        __syncthreads();                                                    // (1)
+        __syncthreads();                                                    // (2)
+        int cur = 0;
+        PAIR_T0();
+        for (int t = lb; t < ntiles; t += nb, cur ^= 1) {
+            // 8 k-steps x (1 eff + 9 image fragments, two transposed LDS reads each) as a software pipeline over 24 groups of three
+            // image fragments (the first group of a k-step also carries the eff fragment): group j+2 is requested while group j is
+            // multiplied, so 12-14 LDS reads stay in flight (lgkmcnt holds 15) instead of every k-step waiting for its own 20 reads
+            // (7 200 cycles per wave and tile in the phase counters against 2 300 of MFMA issue).  The waits are placed by hand in front
+            // of the new requests -- left to itself the compiler sinks the requests behind the MFMAs or waits for all of them.
+            bf16x8_t fr[3][3], fb[2];
             // k-step ks reads 16 rows further down: + ks * 4096 B in the image (row & 15, hence the swizzle, is unchanged) and
             // + ks * 1024 B in the eff tile -- immediates of the read instructions; 18 + 1 address registers serve all 160 reads
-            const char* ibase = smem + image;
-            const char* ebase = smem + effb + b_off0;
+            const char* ibase = smem + cur * img_bytes;
+            const char* ebase = smem + eff_off + cur * TP * 64 + b_off0;
             auto issue = [&](int j) {                                          // j = 3 * ks + third
                 const int ks = j / 3, third = j - 3 * ks;
                 if (third == 0) fb[ks & 1] = tr_frag(ebase, ks * 1024, ks * 1024 + 256);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const int tap = third * 3 + i;
-                    fa[j % 3][i] = tr_frag(ibase, a_lo[tap] + ks * 4096, a_hi[tap] + ks * 4096);
+                    fr[j % 3][i] = tr_frag(ibase, a_lo[tap] + ks * 4096, a_hi[tap] + ks * 4096);
                 }
             };
             constexpr int NG = 3 * (TP / 16);
@@ -720,42 +742,28 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                 const int ks = j / 3, third = j - 3 * ks;
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    acc[third * 3 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j % 3][i], fb[ks & 1], acc[third * 3 + i], 0, 0, 0);
+                    acc[third * 3 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j % 3][i], fb[ks & 1], acc[third * 3 + i], 0, 0, 0);
             }
+            PAIR_PH(0);
+            __syncthreads();                                                // (tile)
+            PAIR_PH(1);
         }
-        PAIR_PH(2);
-        if (more) {
+        // dW[tap*128 + c][n] ; rows of the C tile are this wave's channels, columns the 32 output channels
+        const int n = lane & 31, hh = lane >> 5;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) eff_store(cur ^ 1, i, mm[i], gv[i], xv[i]);
-        }
-        PAIR_PH(3);
-        if (t + 2 * nb < ntiles) fill_tbl(tnn, t + 2 * nb);
-        PAIR_PH(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PAIR_PH(5);
-        __syncthreads();
-        PAIR_PH(6);
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = w4 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                g.slab[(long)blockIdx.x * (9 * 128 * 32) + ((long)tap * 128 + c) * 32 + n] = acc[tap][i];
+            }
     }
 #ifdef TCVN_DEBUG_KNOBS
     if (lane == 0 && (blockIdx.x & 15) == 0)
         for (int i = 0; i < 16; ++i)
             if (ph[i]) atomicAdd(&g_wg_ph[i], ph[i]);
 #endif
-
-    // dW[tap*128 + c][n] += acc ; rows of the C tile are this wave's channels, columns the 32 output channels
-    const int n = lane & 31, hh = lane >> 5;
-    {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                g.slab[(long)blockIdx.x * (9 * 128 * 32) + ((long)tap * 128 + c) * 32 + n] = acc[tap][i];
-            }
-    }
     if (g.dbias != nullptr) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bred[ra * 32 + ec * 8 + j] = bsum[j];
         __syncthreads();
         if (tid < 32) {
             float sum = 0.f;
@@ -1215,10 +1223,9 @@ int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st) {
     if (a.slab == nullptr || (long)nb * (9 * 128 * 32 + 32) * 4 > a.slab_bytes || a.dbias == nullptr) return -3;
     {
         ProfScope ps("k_conv3x3_wgrad_bf16", 2.0 * a.fa.M * (double)a.e.N * a.fa.K, (double)a.fa.M * 2.0 * (a.fa.C + 2 * a.e.N), st);   // YA + (G, x) slices
-        // (a ring variant of this kernel -- consecutive tiles, 128 new image rows per step instead of the whole 70 KB image, batched table
-        //  reads -- measured 378 us against 360-375 us for block 1: the image re-fetch comes from L2 and is not what bounds it)
-        hipLaunchKernelGGL(k_conv3x3_wgrad_bf16, dim3(nb), dim3(256), wgrad_smem(q), st, a, n_img, ntiles,
-                           (nb >= 8 && nb % 8 == 0) ? 1 : 0);
+        // (a ring variant of the one-role kernel -- consecutive tiles, 128 new image rows per step instead of the whole 70 KB image --
+        //  measured 378 us against 360-375 us for block 1)
+        hipLaunchKernelGGL(k_conv3x3_wgrad_bf16, dim3(nb), dim3(512), wgrad_smem(q), st, a, n_img, ntiles, (nb >= 8 && nb % 8 == 0) ? 1 : 0);
         TCVN_LAUNCH_CHECK();
     }
     // weight partials [nb][9*128*32] -> dWk and bias partials [nb][32] -> dbias[0:N) (32-wide rows, zero beyond N): one launch

@@ -34,8 +34,8 @@ for name, ms, fl, by in _lib.profile_records():
 v = list(buf)
 tiles = (n * 101 * 71 + 127) // 128
 waves = 4 * tiles / 16       # wave-tiles that report (every 16th workgroup)
-names = ["dma issue (table reads + 21 DMA)", "eff loads issue", "k loop (tr reads + 72 MFMA)", "eff store (dropout hash)", "table fill",
-         "wait vmcnt(0)", "barrier"]
-for k, nm in enumerate(names):
-    print(f"{nm:36s} {v[k] / 1e6:10.1f} Mcycles   {v[k] / waves:8.0f} cycles per wave and tile")
-print("tiles", tiles, "sum", sum(v) / waves)
+names = {0: "M k loop (tr reads + 72 MFMA)", 1: "M barrier", 8: "H dma issue (17 DMA)", 9: "H eff loads + store (hash)",
+         10: "H table fill", 11: "H wait vmcnt(0)", 12: "H barrier"}
+for k in sorted(names):
+    print(f"{names[k]:36s} {v[k] / 1e6:10.1f} Mcycles   {v[k] / waves:8.0f} cycles per wave and tile")
+print("tiles", tiles, "sum M", sum(v[:8]) / waves, "sum H", sum(v[8:]) / waves)
