@@ -421,6 +421,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
         for (int e = 0; e < 16; ++e) mrow[e] = tbl[((te - t0) * TP + q.halo + pw * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) & (PAIR_TBL - 1)];
         float f1 = 0.f, f2 = 0.f;
         bf16* ct = ctile + pw * 32 * 32;                                              // this pair's [32 positions][32 channels] bf16 tile (wave private)
+        uint32_t kword = 0;                                                           // lane L < 32: keep flags of position pos(e = L >> 1, h = L & 1)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = mrow[e];
@@ -428,7 +429,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
             float v = mine[e] + part[e] + bias;
             if (DROP) {
                 const int mm = m < 0 ? 0 : m;
-                v *= drop_pick(drop_bits32(dkey, mm, r, g.N), mm, g.drop_p);          // (the launcher checks pixels * N < 2^32)
+                const float dsc = drop_pick(drop_bits32(dkey, mm, r, g.N), mm, g.drop_p);   // (the launcher checks pixels * N < 2^32)
+                v *= dsc;
+                // the 32 channels of a position sit in the 32 lanes of a wave half: one ballot = the keep words of two positions
+                const unsigned long long bal = __ballot(dsc != 0.f);
+                kword = lane == 2 * e ? (uint32_t)bal : lane == 2 * e + 1 ? (uint32_t)(bal >> 32) : kword;
             }
             const bf16 o = ok ? f2bf(v) : (bf16)0;
             const float x = bf2f(o);                                                  // 0 for padding positions / absent channels
@@ -437,6 +442,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
             else if (ok) Out[(long)m * g.ldo + g.n_off + r] = o;
         }
         s1 += (double)f1; s2 += (double)f2;
+        if (DROP && g.keep_out != nullptr && lane < 32) {                                 // the backward kernels test these bits instead of hashing
+            const int el = lane >> 1, pos = (el & 3) + 8 * (el >> 2) + 4 * (lane & 1);
+            const int m = tbl[((te - t0) * TP + q.halo + pw * 32 + pos) & (PAIR_TBL - 1)];
+            if (m >= 0) g.keep_out[m] = kword;
+        }
         if (VEC) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {                                             // 32 positions x 64 B = 128 chunks of 16 B, two per lane
@@ -621,22 +631,27 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
             const int n = ec * 8 + j;
             cP[j] = n < e.N ? e.P[n] : 0.f; cQ[j] = n < e.N ? e.Q[n] : 0.f; bsum[j] = 0.f;
         }
-        auto eff_load = [&](const int* rowpix, int i, u16x8& gv, u16x8& xv) -> int {
+        const uint32_t* __restrict__ KM = e.keep;                          // keep words written by the forward kernel (or nullptr: hash)
+        const float dinv = 1.f / (1.f - e.drop_p);
+        auto eff_load = [&](const int* rowpix, int i, u16x8& gv, u16x8& xv, uint32_t& kw) -> int {
             const int m = rowpix[q.halo + ra + 64 * i];
             const long o = (long)(m >= 0 ? m : 0);
             gv = *reinterpret_cast<const u16x8*>(G + o * e.ldg + e.c_off + ec * 8);
             xv = *reinterpret_cast<const u16x8*>(D + o * e.ldx + e.c_off + ec * 8);
+            kw = KM != nullptr ? KM[o] : 0u;
             return m;
         };
-        auto eff_store = [&](int buf, int i, int m, const u16x8& gv, const u16x8& xv) {
+        auto eff_store = [&](int buf, int i, int m, const u16x8& gv, const u16x8& xv, uint32_t kw) {
             u16x8 o;
+            const uint32_t kb = kw >> (ec * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float t = 0.f;
                 const int n = ec * 8 + j;
                 if (m >= 0 && n < e.N) {
                     t = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
-                    if (drop) t *= drop_pick(drop_bits32(dkey, m, n, e.N), m, e.drop_p);      // (pixels * N < 2^32: conv3x3_wgrad_tile_ok)
+                    if (drop) t *= KM != nullptr ? (((kb >> j) & 1u) ? dinv : 0.f)
+                                                 : drop_pick(drop_bits32(dkey, m, n, e.N), m, e.drop_p);      // (pixels * N < 2^32: conv3x3_wgrad_tile_ok)
                 }
                 o[j] = f2bf(t);
                 bsum[j] += bf2f(o[j]);
@@ -652,7 +667,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         if (lb < ntiles) {
             dma_image(smem, 0, YA, zeros, tbl, nrows4, w4, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { u16x8 gv, xv; const int m = eff_load(tbl, i, gv, xv); eff_store(0, i, m, gv, xv); }
+            for (int i = 0; i < 2; ++i) { u16x8 gv, xv; uint32_t kw; const int m = eff_load(tbl, i, gv, xv, kw); eff_store(0, i, m, gv, xv, kw); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                                    // (2)
@@ -664,11 +679,12 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                 dma_image(smem, (cur ^ 1) * img_bytes, YA, zeros, tbl + tn * nrows4, nrows4, w4, lane);
                 PAIR_PH(8);
                 u16x8 gv[2], xv[2];
+                uint32_t kw[2];
                 int mm[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) mm[i] = eff_load(tbl + tn * nrows4, i, gv[i], xv[i]);
+                for (int i = 0; i < 2; ++i) mm[i] = eff_load(tbl + tn * nrows4, i, gv[i], xv[i], kw[i]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) eff_store(cur ^ 1, i, mm[i], gv[i], xv[i]);
+                for (int i = 0; i < 2; ++i) eff_store(cur ^ 1, i, mm[i], gv[i], xv[i], kw[i]);
                 PAIR_PH(9);
             }
             if (t + 2 * nb < ntiles) fill_tbl(tnn, t + 2 * nb);
@@ -928,6 +944,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
     const int nr = (q.rows() + 15) & ~15;                       // image rows, whole DMA row groups (16 rows x 64 B = 1 KiB)
     constexpr int CLD3 = 132;
     const int o_rg = nr * 64, o_rd = 2 * nr * 64, o_tbl = 3 * nr * 64, o_cs = o_tbl + 2 * nr * 4;     // eff image at 0
+    const int o_km = o_cs + 32 * 132 * 4 + 448 * 4;             // [nr rounded up to 64] keep words of the tile's rows (when the forward stored them)
     int* tbl = reinterpret_cast<int*>(smem + o_tbl);            // [2][nr] pixel index per image row (this tile / next tile)
     float* Cs = reinterpret_cast<float*>(smem + o_cs);          // [32][CLD3] fp32 dA rows of one pass
     double* red = reinterpret_cast<double*>(smem + o_cs);       // [4][128][3] after the last tile
@@ -961,8 +978,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
     auto fill_tbl = [&](int slot, int tile) {
         for (int rr = tid; rr < nr; rr += 256) tbl[slot * nr + rr] = pix_of(q, tile * TP - q.halo + rr, invWp, invHp);
     };
+    const uint32_t* __restrict__ KM = e.keep;                    // keep words of the forward kernel (or nullptr: hash)
+    const float dinv = 1.f / (1.f - e.drop_p);
     auto dma_raw = [&](int slot) {                              // both slices, this wave's row groups; padding rows <- zeros
         const int rsub = lane >> 2, chunk = lane & 3;
+        if (KM != nullptr) {                                    // one word per row: 64 rows per instruction (lane = row), 4 B per lane
+            for (int r64 = wave; r64 * 64 < nr; r64 += 4) {
+                const int rr = r64 * 64 + lane;
+                const int m = rr < nr ? tbl[slot * nr + rr] : -1;
+                const char* sk = m >= 0 ? reinterpret_cast<const char*>(KM + m) : zeros;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sk,
+                                                 (__attribute__((address_space(3))) void*)(smem + o_km + r64 * 256), 4, 0, 0);
+            }
+        }
         for (int rg = wave; rg * 16 < nr; rg += 4) {
             const int m = tbl[slot * nr + rg * 16 + rsub];
             const char* sg = m >= 0 ? reinterpret_cast<const char*>(G + (long)m * e.ldg + e.c_off) + chunk * 16 : zeros + chunk * 16;
@@ -1008,10 +1036,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
             if (m >= 0 && !TCVN_DBG_BIT(dbg, 8)) {
                 const u16x8 gv = *reinterpret_cast<const u16x8*>(smem + o_rg + rr * 64 + ec * 16);
                 const u16x8 xv = *reinterpret_cast<const u16x8*>(smem + o_rd + rr * 64 + ec * 16);
+                const uint32_t kb = KM != nullptr ? *reinterpret_cast<const uint32_t*>(smem + o_km + rr * 4) >> (ec * 8) : 0u;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float v = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
-                    if (drop) v *= drop_pick(drop_bits32(dkey, m, ec * 8 + j, e.N), m, e.drop_p);      // (pixels * N < 2^32: conv3x3_dgrad_tile_ok)
+                    if (drop) v *= KM != nullptr ? (((kb >> j) & 1u) ? dinv : 0.f)
+                                                 : drop_pick(drop_bits32(dkey, m, ec * 8 + j, e.N), m, e.drop_p);      // (pixels * N < 2^32: conv3x3_dgrad_tile_ok)
                     o[j] = f2bf(v);
                 }
             }
@@ -1111,7 +1141,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
     }
 }
 
-size_t dgrad2_smem(const PadGeom& q) { const size_t nr = (q.rows() + 15) & ~15; return 3 * nr * 64 + 2 * nr * 4 + 32 * 132 * 4 + 448 * 4; }
+size_t dgrad2_smem(const PadGeom& q) { const size_t nr = (q.rows() + 15) & ~15; return 3 * nr * 64 + 2 * nr * 4 + 32 * 132 * 4 + 448 * 4 + ((nr + 63) & ~size_t(63)) * 4; }
 size_t dgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return r4 * 68 + 128 * 24 + 64 * 132 * 4; }
 int tile_grid2(long ntiles) {           // two workgroups per CU
     if (ntiles >= 512) return 512;
@@ -1152,6 +1182,15 @@ int conv3x3_tile_nblk(const ConvFwdArgs& a) {
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
     return tile_grid(q.tiles());
 }
+static bool fwd_pair_ok(const ConvFwdArgs& a, const PadGeom& q, int dbg) {
+    return fwd_pair_smem(q) <= 160 * 1024 && 4 * TP + q.halo + q.Wp + 1 < PAIR_TBL && (long)a.M * a.N < (1L << 32) && !TCVN_DBG_BIT(dbg, 32) &&
+           !TCVN_DBG_BIT(dbg, 64);
+}
+bool conv3x3_fwd_writes_keep(const ConvFwdArgs& a) {
+    if (a.keep_out == nullptr || a.drop_p <= 0.f || !conv3x3_tile_ok(a)) return false;
+    [[maybe_unused]] static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
+    return fwd_pair_ok(a, PadGeom(a.M / (a.H * a.W), a.H, a.W), dbg);
+}
 int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
     const int n_img = a.M / (a.H * a.W);
     const PadGeom q(n_img, a.H, a.W);
@@ -1168,7 +1207,7 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
     ConvFwdArgs b = a;
     static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
     b.dbg = dbg;
-    if (fwd_pair_smem(q) <= 160 * 1024 && 4 * TP + q.halo + q.Wp + 1 < PAIR_TBL && (long)a.M * a.N < (1L << 32) && !TCVN_DBG_BIT(dbg, 32) && !TCVN_DBG_BIT(dbg, 64)) {   // two waves per SIMD, taps split (TCVN_DBG=64: one-wave ring kernel)
+    if (fwd_pair_ok(a, q, dbg)) {   // two waves per SIMD, taps split (TCVN_DBG=64: one-wave ring kernel)
         static bool attr3 = false;
         if (!attr3) {
             TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_fwd_pair_bf16), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -125,7 +125,7 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
     const int mid = cfg.bn_size * cfg.growth;
     L.img = b.take((long)n * cfg.H * cfg.W * cfg.in_ch * esz);
     L.c0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
-    L.D.clear(); L.Y.clear(); L.bstatD.clear(); L.bstatY.clear(); L.YA.clear(); L.XA.clear(); L.XP.clear();
+    L.D.clear(); L.Y.clear(); L.bstatD.clear(); L.bstatY.clear(); L.YA.clear(); L.XA.clear(); L.XP.clear(); L.KM.clear();
     L.zeros = b.take(1024);
     L.sidx = sparse_stem_possible() ? b.take(stem_sparse_index_bytes(n, cfg.H, cfg.W)) : -1;
     long max_part = (long)pool0_grid(n, blocks[0].H, blocks[0].W) * cfg.init_ch * 16;
@@ -142,6 +142,10 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
         if (cfg.mode == MODE_BF16)
             for (int l = 0; l < bg.L; ++l) yas.push_back(b.take(M * mid * esz));
         L.YA.push_back(yas);
+        std::vector<long> kms;
+        if (cfg.mode == MODE_BF16 && cfg.dropout > 0.f)
+            for (int l = 0; l < bg.L; ++l) kms.push_back(b.take(M * 4));
+        L.KM.push_back(kms);
         std::vector<long> xas;
         for (int l = 0; l < bg.L; ++l) {
             const int cin = bg.C0 + l * cfg.growth;
@@ -504,6 +508,12 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 a.part = train ? part : nullptr;
                 a.drop_p = train ? cfg.dropout : 0.f; a.seed = seed; a.stream_id = (uint32_t)(bi * 64 + l + 1);
                 a.nblk = conv_fwd_nblk(a);
+                if (train && !L.KM[bi].empty()) {           // the pair kernel leaves the keep flags it drew for the backward kernels
+                    a.keep_out = reinterpret_cast<uint32_t*>(ws + L.KM[bi][l]);
+                    if (keep_valid.size() != blocks.size()) keep_valid.assign(blocks.size(), std::vector<char>());
+                    if ((int)keep_valid[bi].size() != bg.L) keep_valid[bi].assign(bg.L, 0);
+                    keep_valid[bi][l] = conv3x3_fwd_writes_keep(a) ? 1 : 0;
+                }
                 if ((rc = conv_fwd(a, st))) return rc;
                 new_c0 = ls.cin; new_n = g; new_nblk = a.nblk; new_ld = g;
             }

@@ -243,6 +243,8 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             const uint32_t sid = (uint32_t)(bi * 64 + l + 1);
             // gradient of this layer's output slice D[:, cin:cin+g]
             EffSrc e2{G, bg.ld, D, bg.ld, ls.cin, g, P + ls.cin, Q + ls.cin, cfg.dropout, seed, sid};
+            if (bi < (int)keep_valid.size() && l < (int)keep_valid[bi].size() && keep_valid[bi][l] && !L.KM[bi].empty())
+                e2.keep = reinterpret_cast<const uint32_t*>(ws + L.KM[bi][l]);      // keep words of this layer's forward (else: the hash)
             {   // conv2 (3x3) weight gradient
                 const WkEntry& ef = wk_find(ls.w2, 0);
                 ConvWgradArgs w{};

@@ -23,6 +23,7 @@ struct Layout {
     long img, c0, bstat0, part, tabs, F, Z, head_stat, wk, fwd_end, total;
     std::vector<long> D, bstatD;
     std::vector<std::vector<long>> Y, bstatY, YA;     // YA: activated bf16 copies of Y (bf16 mode)
+    std::vector<std::vector<long>> KM;                // bf16 mode with dropout: one keep word per pixel and dense layer (3x3 output dropout)
     long zeros, ey, ey2, slab;
     long sidx;                           // sparse-stem bucket index (stem_sparse.hip), -1 when the plan cannot use it
     std::vector<std::vector<long>> XA;   // activated bf16 copies of the 1x1-conv inputs (per layer, -1 if absent)
@@ -55,6 +56,7 @@ struct DenseNetPlan {
     uint64_t last_seed = 0; int last_n = 0;
     const int32_t* last_coords = nullptr; long last_nnz = 0;     // COO list of the last forward (sparse stem weight gradient)
     const float* last_values = nullptr; int last_value_mode = 0; float last_noise = 0.f;
+    std::vector<std::vector<char>> keep_valid;   // [block][layer]: the last train-mode forward stored the layer's dropout keep words
     bool last_fused_ya = false;          // the last forward was an eval pass whose 1x1 GEMMs wrote the activated bottleneck maps only (no raw Y)
     bool last_sparse_stem = false;       // the last forward ran the sparse-aware stem: no dense map / conv0 output exists (backward must match)
     bool sparse_stem_possible() const;   // plan-level condition (bf16, 3 -> 64 channels); the hit count decides per call

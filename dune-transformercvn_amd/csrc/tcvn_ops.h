@@ -29,8 +29,10 @@ struct ConvFwdArgs {
     const void* zeros;               // >= 256 B of zeros in device memory (source of padding rows for LDS-DMA)
     double* part; int nblk;          // [nblk][N][2]; nblk = grid.x
     float drop_p; uint64_t seed; uint32_t stream_id;
+    uint32_t* keep_out;              // optional [M]: the 3x3 pair kernel stores the keep flags of a pixel's N <= 32 channels as one word
 };
 int conv_fwd(const ConvFwdArgs& a, hipStream_t st);
+bool conv3x3_fwd_writes_keep(const ConvFwdArgs& a);   // true when conv_fwd(a) runs the kernel that fills keep_out
 int conv_fwd_grid(int M);            // number of M-blocks of the generic kernels for M rows (<= 512)
 int conv_fwd_nblk(const ConvFwdArgs& a);   // grid.x (== rows of `part`) conv_fwd will use for these arguments (<= 512)
 // bf16 3x3 fast path on padded LDS tiles (conv3x3_tile.hip)
@@ -103,6 +105,8 @@ struct EffSrc {
     int c_off, N;
     const float *P, *Q;
     float drop_p; uint64_t seed; uint32_t stream_id;
+    const uint32_t* keep;            // optional (bf16 tile kernels): bit n of keep[m] = dropout keep flag of channel n of pixel m, as the
+                                     // forward kernel drew it (ConvFwdArgs::keep_out) -- a bit test instead of the hash per element
 };
 
 enum DMode { DG_1X1 = 0, DG_1X1_POOL = 1, DG_3X3 = 2 };
