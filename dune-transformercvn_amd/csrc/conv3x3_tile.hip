@@ -589,28 +589,66 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* smem_base, int off_lo, i
     return __builtin_bit_cast(bf16x8_t, pr);
 }
 
+constexpr int WG_RING = 512, WG_TBL = 1024;
+template <bool WRAP>
+__device__ __forceinline__ void wg_kloop(f32x16 (&acc)[9], const char* smem, int base_bytes, const int (&a_lo)[9], const int (&a_hi)[9],
+                                         const char* ebase) {
+    bf16x8_t fr[3][3], fb[2];
+    auto issue = [&](int j) {                                       // j = 3 * ks + third
+        const int ks = j / 3, third = j - 3 * ks;
+        if (third == 0) fb[ks & 1] = tr_frag(ebase, ks * 1024, ks * 1024 + 256);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int tap = third * 3 + i;
+            if (WRAP) fr[j % 3][i] = tr_frag(smem, (a_lo[tap] + base_bytes + ks * 4096) & (WG_RING * 256 - 1),
+                                             (a_hi[tap] + base_bytes + ks * 4096) & (WG_RING * 256 - 1));
+            else fr[j % 3][i] = tr_frag(smem + base_bytes, a_lo[tap] + ks * 4096, a_hi[tap] + ks * 4096);
+        }
+    };
+    constexpr int NG = 3 * (TP / 16);
+    issue(0);
+    issue(1);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        // group j complete <=> at most the reads of group j+1 outstanding (6, or 8 when it opens a k-step)
+        if (j + 1 < NG) { if ((j + 1) % 3 == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (8 << 8)); else __builtin_amdgcn_s_waitcnt(0xC07F | (6 << 8)); }
+        else __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 2 < NG) issue(j + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = j / 3, third = j - 3 * ks;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            acc[third * 3 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j % 3][i], fb[ks & 1], acc[third * 3 + i], 0, 0, 0);
+    }
+}
+
 // Two waves per SIMD with different roles (as in the forward pair kernel): 512 threads.  Waves 0-3 only multiply -- the pipelined
-// fragment reads + 72 MFMAs of tile t.  Waves 4-7 prepare tile t+1 meanwhile: image DMA (whose issue stalls while the memory pipe is
-// full: 4 900 cycles per tile in the phase counters, with nothing left to wait for afterwards), the eff tile (slice loads, BatchNorm
-// mean terms, dropout hash: 3 700), the pixel table of tile t+2 (1 100).  One barrier per tile.  The one-role kernel ran those 9 700
-// cycles and the 5 300 of the k loop one after the other in every wave.  The roles are separate code paths (separate live ranges:
-// 144 accumulators + fragments on one side, tables and hash state on the other; a merged body needs more than the 256 registers
-// two waves per SIMD leave each).
-__global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradArgs g, int n_img, int ntiles, int swz) {
+// fragment reads + 72 MFMAs of tile t.  Waves 4-7 prepare tile t+1 meanwhile: image rows by LDS-DMA, the eff tile (slice loads,
+// BatchNorm mean terms, dropout keep bits), the pixel table of tile t+2.  One barrier per tile.
+// A workgroup walks CONSECUTIVE tiles and keeps the image in a ring of WG_RING = 512 rows (128 KB): tile t+1 shares all but its last
+// 128 rows with tile t, so only those are fetched -- 32 KB per tile instead of the whole 70 KB image (272 rows at W = 69).  The phase
+// counters of the one-image-per-tile version showed the helper waves, not the MFMAs, bounding the tile: 6 700 cycles stalled in the DMA
+// issue and 5 100 more until the slice loads queued behind it returned, i.e. the kernel moved its 2.1x redundant image traffic at
+// the HBM rate (3.2 TB/s) while the multiplying waves waited 9 600 of 13 700 cycles at the barrier.
+// Row space of a workgroup: row 0 = padded position t0 * TP - halo; ring slot = row & 511; table entry = row & 1023; the XOR
+// swizzle of a row's 16-B chunks uses row & 15 (TP and the ring are multiples of 16, so it equals the tile-relative row & 15).
+__global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradArgs g, int n_img, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvFwdArgs& fa = g.fa;
     const EffSrc& e = g.e;
     const PadGeom q(n_img, fa.H, fa.W);
     const int nrows4 = (q.rows() + 3) & ~3;
-    const int img_bytes = nrows4 * 256;
-    const int eff_off = 2 * img_bytes;                                    // two [TP][32] bf16 images, 64-B rows, unswizzled
-    int* tbl = reinterpret_cast<int*>(smem + eff_off + 2 * TP * 64);      // [3][nrows4]
-    float* bred = reinterpret_cast<float*>(smem + eff_off);        // [64][32], aliases the eff images after the last barrier
+    constexpr int eff_off = WG_RING * 256;                                // two [TP][32] bf16 tiles behind the ring, 64-B rows, unswizzled
+    int* tbl = reinterpret_cast<int*>(smem + eff_off + 2 * TP * 64);      // [1024] pixel index of row (row & 1023)
+    float* bred = reinterpret_cast<float*>(smem + eff_off);               // [64][32], aliases the eff tiles after the last barrier
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w4 = wave & 3, htid = tid & 255;                             // wave / thread index inside the role
-    const int nb = gridDim.x;
-    const int lb = swz ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int nb = gridDim.x, per = ntiles / nb, rem = ntiles % nb;
+    const int t0 = blockIdx.x * per + min((int)blockIdx.x, rem), t1 = t0 + per + ((int)blockIdx.x < rem ? 1 : 0);
+    const int g_org = t0 * TP - q.halo;
 #ifdef TCVN_DEBUG_KNOBS
     unsigned long long ph[16] = {0};
 #endif
@@ -633,8 +671,8 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         }
         const uint32_t* __restrict__ KM = e.keep;                          // keep words written by the forward kernel (or nullptr: hash)
         const float dinv = 1.f / (1.f - e.drop_p);
-        auto eff_load = [&](const int* rowpix, int i, u16x8& gv, u16x8& xv, uint32_t& kw) -> int {
-            const int m = rowpix[q.halo + ra + 64 * i];
+        auto eff_load = [&](int row0, int i, u16x8& gv, u16x8& xv, uint32_t& kw) -> int {      // row0: first body row of the tile
+            const int m = tbl[(row0 + ra + 64 * i) & (WG_TBL - 1)];
             const long o = (long)(m >= 0 ? m : 0);
             gv = *reinterpret_cast<const u16x8*>(G + o * e.ldg + e.c_off + ec * 8);
             xv = *reinterpret_cast<const u16x8*>(D + o * e.ldx + e.c_off + ec * 8);
@@ -658,36 +696,57 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
             }
             *reinterpret_cast<u16x8*>(smem + eff_off + buf * TP * 64 + (ra + 64 * i) * 64 + ec * 16) = o;
         };
-        auto fill_tbl = [&](int slot, int tile) {
-            for (int rr = htid; rr < nrows4; rr += 256) tbl[slot * nrows4 + rr] = pix_of(q, tile * TP - q.halo + rr, invWp, invHp);
+        auto fill_rows = [&](int row0, int n) {                            // table entries of rows [row0, row0 + n)
+            for (int i = htid; i < n; i += 256) tbl[(row0 + i) & (WG_TBL - 1)] = pix_of(q, g_org + row0 + i, invWp, invHp);
         };
-        if (lb < ntiles) fill_tbl(0, lb);
-        if (lb + nb < ntiles) fill_tbl(1, lb + nb);
-        __syncthreads();                                                    // (1)
-        if (lb < ntiles) {
-            dma_image(smem, 0, YA, zeros, tbl, nrows4, w4, lane);
+        // rows [row0, row0 + n) -> ring (n multiple of 4): 4 rows = 1 KiB per wave instruction; all table reads first, then the DMAs
+        auto dma_rows = [&](int row0, int n) {
+            const int rsub = lane >> 4, slot = lane & 15;
+            constexpr int DMA_RG = 24;                                     // row groups per wave: up to 384 rows per call
+            int mrow[DMA_RG];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { u16x8 gv, xv; uint32_t kw; const int m = eff_load(tbl, i, gv, xv, kw); eff_store(0, i, m, gv, xv, kw); }
+            for (int i = 0; i < DMA_RG; ++i) {
+                const int rg = w4 + 4 * i;
+                mrow[i] = rg * 4 < n ? tbl[(row0 + rg * 4 + rsub) & (WG_TBL - 1)] : -1;
+            }
+#pragma unroll
+            for (int i = 0; i < DMA_RG; ++i) {
+                const int rg = w4 + 4 * i;
+                if (rg * 4 < n) {
+                    const int row = row0 + rg * 4, rr = row + rsub;       // row0 multiple of 4: the group stays inside the ring
+                    const char* src = mrow[i] >= 0 ? reinterpret_cast<const char*>(YA + (long)mrow[i] * 128) + ((slot ^ (rr & 15)) << 4)
+                                                   : zeros + (slot << 4);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(smem + (row & (WG_RING - 1)) * 256), 16, 0, 0);
+                }
+            }
+        };
+        if (t0 < t1) fill_rows(0, nrows4 + (t0 + 1 < t1 ? TP : 0));       // tile t0's image rows and the new rows of tile t0 + 1
+        __syncthreads();                                                    // (1)
+        if (t0 < t1) {
+            dma_rows(0, nrows4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { u16x8 gv, xv; uint32_t kw; const int m = eff_load(q.halo, i, gv, xv, kw); eff_store(0, i, m, gv, xv, kw); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                                    // (2)
-        int cur = 0, ts = 0;
+        int cur = 0;
         PAIR_T0();
-        for (int t = lb; t < ntiles; t += nb, cur ^= 1, ts = ts == 2 ? 0 : ts + 1) {
-            const int tn = ts == 2 ? 0 : ts + 1, tnn = tn == 2 ? 0 : tn + 1;
-            if (t + nb < ntiles) {
-                dma_image(smem, (cur ^ 1) * img_bytes, YA, zeros, tbl + tn * nrows4, nrows4, w4, lane);
+        for (int t = t0; t < t1; ++t, cur ^= 1) {
+            const int i1 = t - t0 + 1;                                     // local index of the tile being prepared
+            if (t + 1 < t1) {
+                dma_rows((i1 - 1) * TP + nrows4, TP);                      // the 128 rows tile t+1 does not share with tile t
                 PAIR_PH(8);
                 u16x8 gv[2], xv[2];
                 uint32_t kw[2];
                 int mm[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) mm[i] = eff_load(tbl + tn * nrows4, i, gv[i], xv[i], kw[i]);
+                for (int i = 0; i < 2; ++i) mm[i] = eff_load(i1 * TP + q.halo, i, gv[i], xv[i], kw[i]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) eff_store(cur ^ 1, i, mm[i], gv[i], xv[i], kw[i]);
                 PAIR_PH(9);
             }
-            if (t + 2 * nb < ntiles) fill_tbl(tnn, t + 2 * nb);
+            if (t + 2 < t1) fill_rows(i1 * TP + nrows4, TP);               // new rows of tile t+2
             PAIR_PH(10);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PAIR_PH(11);
@@ -710,7 +769,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         const int khalf = gq >> 1, chalf = gq & 1;
         const int a_chunk = w4 * 4 + 2 * chalf + (tp >> 1), a_sub = (tp & 1) * 8;         // Yact: this wave's 32 channels
         const int b_colbyte = (16 * chalf + 4 * tp) * 2;                                  // eff: 32 channels
-        // image offsets of this lane's two transposed reads per tap at k-step 0 (rows arow and arow + 4 of the padded tile)
+        // byte offsets of this lane's two transposed reads per tap at k-step 0, relative to the tile's first image row
         int a_lo[9], a_hi[9];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -723,43 +782,17 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         __syncthreads();                                                    // (2)
         int cur = 0;
         PAIR_T0();
-        for (int t = lb; t < ntiles; t += nb, cur ^= 1) {
-            // 8 k-steps x (1 eff + 9 image fragments, two transposed LDS reads each) as a software pipeline over 24 groups of three
-            // image fragments (the first group of a k-step also carries the eff fragment): group j+2 is requested while group j is
-            // multiplied, so 12-14 LDS reads stay in flight (lgkmcnt holds 15) instead of every k-step waiting for its own 20 reads
-            // (7 200 cycles per wave and tile in the phase counters against 2 300 of MFMA issue).  The waits are placed by hand in front
-            // of the new requests -- left to itself the compiler sinks the requests behind the MFMAs or waits for all of them.
-            bf16x8_t fr[3][3], fb[2];
-            // k-step ks reads 16 rows further down: + ks * 4096 B in the image (row & 15, hence the swizzle, is unchanged) and
-            // + ks * 1024 B in the eff tile -- immediates of the read instructions; 18 + 1 address registers serve all 160 reads
-            const char* ibase = smem + cur * img_bytes;
+        // 8 k-steps x (1 eff + 9 image fragments, two transposed LDS reads each) as a software pipeline over 24 groups of three image
+        // fragments (the first group of a k-step also carries the eff fragment): group j+2 is requested while group j is multiplied, so
+        // 12-14 LDS reads stay in flight (lgkmcnt holds 15) instead of every k-step waiting for its own 20 reads (7 200 cycles per wave and
+        // tile in the phase counters against 2 300 of MFMA issue).  The waits are placed by hand in front of the new requests -- left to
+        // itself the compiler sinks the requests behind the MFMAs or waits for all of them.
+        for (int t = t0; t < t1; ++t, cur ^= 1) {
+            const int base_row = ((t - t0) * TP) & (WG_RING - 1);
             const char* ebase = smem + eff_off + cur * TP * 64 + b_off0;
-            auto issue = [&](int j) {                                          // j = 3 * ks + third
-                const int ks = j / 3, third = j - 3 * ks;
-                if (third == 0) fb[ks & 1] = tr_frag(ebase, ks * 1024, ks * 1024 + 256);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int tap = third * 3 + i;
-                    fr[j % 3][i] = tr_frag(ibase, a_lo[tap] + ks * 4096, a_hi[tap] + ks * 4096);
-                }
-            };
-            constexpr int NG = 3 * (TP / 16);
-            issue(0);
-            issue(1);
-#pragma unroll
-            for (int j = 0; j < NG; ++j) {
-                __builtin_amdgcn_sched_barrier(0);
-                // group j complete <=> at most the reads of group j+1 outstanding (6, or 8 when it opens a k-step)
-                if (j + 1 < NG) { if ((j + 1) % 3 == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (8 << 8)); else __builtin_amdgcn_s_waitcnt(0xC07F | (6 << 8)); }
-                else __builtin_amdgcn_s_waitcnt(0xC07F);
-                __builtin_amdgcn_sched_barrier(0);
-                if (j + 2 < NG) issue(j + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                const int ks = j / 3, third = j - 3 * ks;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    acc[third * 3 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j % 3][i], fb[ks & 1], acc[third * 3 + i], 0, 0, 0);
-            }
+            // always the masked addressing: two copies of the loop (immediates where the tile does not cross the ring's end) make the
+            // register allocator spill 700+ registers around the branch
+            wg_kloop<true>(acc, smem, base_row * 256, a_lo, a_hi, ebase);
             PAIR_PH(0);
             __syncthreads();                                                // (tile)
             PAIR_PH(1);
@@ -1149,7 +1182,8 @@ int tile_grid2(long ntiles) {           // two workgroups per CU
     return (int)ntiles;
 }
 
-size_t wgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return 2 * r4 * 256 + 2 * TP * 64 + 3 * r4 * 4; }
+// ring + two eff tiles + table; the ring must hold a tile's rows and the 128 rows being fetched for the next one
+size_t wgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return r4 + TP + 8 <= 512 ? size_t(512) * 256 + 2 * TP * 64 + 1024 * 4 : size_t(1) << 30; }
 
 int tile_grid(long ntiles) {            // one persistent workgroup per CU
     [[maybe_unused]] static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
@@ -1262,9 +1296,7 @@ int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st) {
     if (a.slab == nullptr || (long)nb * (9 * 128 * 32 + 32) * 4 > a.slab_bytes || a.dbias == nullptr) return -3;
     {
         ProfScope ps("k_conv3x3_wgrad_bf16", 2.0 * a.fa.M * (double)a.e.N * a.fa.K, (double)a.fa.M * 2.0 * (a.fa.C + 2 * a.e.N), st);   // YA + (G, x) slices
-        // (a ring variant of the one-role kernel -- consecutive tiles, 128 new image rows per step instead of the whole 70 KB image --
-        //  measured 378 us against 360-375 us for block 1)
-        hipLaunchKernelGGL(k_conv3x3_wgrad_bf16, dim3(nb), dim3(512), wgrad_smem(q), st, a, n_img, ntiles, (nb >= 8 && nb % 8 == 0) ? 1 : 0);
+        hipLaunchKernelGGL(k_conv3x3_wgrad_bf16, dim3(nb), dim3(512), wgrad_smem(q), st, a, n_img, ntiles);
         TCVN_LAUNCH_CHECK();
     }
     // weight partials [nb][9*128*32] -> dWk and bias partials [nb][32] -> dbias[0:N) (32-wide rows, zero beyond N): one launch
