@@ -671,12 +671,15 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         }
         const uint32_t* __restrict__ KM = e.keep;                          // keep words written by the forward kernel (or nullptr: hash)
         const float dinv = 1.f / (1.f - e.drop_p);
-        auto eff_load = [&](int row0, int i, u16x8& gv, u16x8& xv, uint32_t& kw) -> int {      // row0: first body row of the tile
-            const int m = tbl[(row0 + ra + 64 * i) & (WG_TBL - 1)];
+        auto eff_fetch = [&](int m, u16x8& gv, u16x8& xv, uint32_t& kw) {                     // slice rows + keep word of pixel m: three loads
             const long o = (long)(m >= 0 ? m : 0);
             gv = *reinterpret_cast<const u16x8*>(G + o * e.ldg + e.c_off + ec * 8);
             xv = *reinterpret_cast<const u16x8*>(D + o * e.ldx + e.c_off + ec * 8);
-            kw = KM != nullptr ? KM[o] : 0u;
+            kw = *(KM != nullptr ? KM + o : reinterpret_cast<const uint32_t*>(zeros));      // always three loads per row (the barrier counts them)
+        };
+        auto eff_load = [&](int row0, int i, u16x8& gv, u16x8& xv, uint32_t& kw) -> int {      // row0: first body row of the tile
+            const int m = tbl[(row0 + ra + 64 * i) & (WG_TBL - 1)];
+            eff_fetch(m, gv, xv, kw);
             return m;
         };
         auto eff_store = [&](int buf, int i, int m, const u16x8& gv, const u16x8& xv, uint32_t kw) {
@@ -721,38 +724,54 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                 }
             }
         };
-        if (t0 < t1) fill_rows(0, nrows4 + (t0 + 1 < t1 ? TP : 0));       // tile t0's image rows and the new rows of tile t0 + 1
+        // Pipeline of the helper role, iteration i (tile t0 + i is being multiplied): eff tile of tile i+1 from the slice rows requested
+        // one iteration earlier (a tile time ago: they have arrived), DMA of tile i+1's new image rows, slice loads of tile i+2,
+        // table entries of tile i+3's new rows.  The barrier waits for the DMAs only -- vmcnt(6): the six slice loads behind them stay in
+        // flight (waiting for them there cost 5 300 cycles per tile, the whole memory latency under load).
+        const int ntl = t1 - t0;
+        if (ntl > 0) fill_rows(0, nrows4 + min(ntl - 1, 2) * TP);          // tile 0's image rows, the new rows of tiles 1 and 2
         __syncthreads();                                                    // (1)
-        if (t0 < t1) {
+        u16x8 gv[2], xv[2];
+        uint32_t kw[2];
+        int mm[2] = {-1, -1};
+        if (ntl > 0) {
             dma_rows(0, nrows4);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { u16x8 gv, xv; uint32_t kw; const int m = eff_load(q.halo, i, gv, xv, kw); eff_store(0, i, m, gv, xv, kw); }
+            for (int i = 0; i < 2; ++i) { u16x8 g0, x0; uint32_t k0; const int m = eff_load(q.halo, i, g0, x0, k0); eff_store(0, i, m, g0, x0, k0); }
+        }
+        if (ntl > 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mm[i] = eff_load(TP + q.halo, i, gv[i], xv[i], kw[i]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                                    // (2)
         int cur = 0;
         PAIR_T0();
-        for (int t = t0; t < t1; ++t, cur ^= 1) {
-            const int i1 = t - t0 + 1;                                     // local index of the tile being prepared
-            if (t + 1 < t1) {
-                dma_rows((i1 - 1) * TP + nrows4, TP);                      // the 128 rows tile t+1 does not share with tile t
-                PAIR_PH(8);
-                u16x8 gv[2], xv[2];
-                uint32_t kw[2];
-                int mm[2];
+        for (int il = 0; il < ntl; ++il, cur ^= 1) {
+            // LDS accesses first, global_load_lds last: the compiler orders every LDS access after a DMA behind vmcnt(0) (the DMA writes LDS).
+            // The explicit vmcnt(0) here is free (the six loads of the previous iteration landed a tile ago) and tells the compiler's
+            // scoreboard so on every path -- without it a vmcnt(0) appears between the DMAs and the loads below.
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (il + 1 < ntl) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) mm[i] = eff_load(i1 * TP + q.halo, i, gv[i], xv[i], kw[i]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) eff_store(cur ^ 1, i, mm[i], gv[i], xv[i], kw[i]);
-                PAIR_PH(9);
+                for (int i = 0; i < 2; ++i) eff_store(cur ^ 1, i, mm[i], gv[i], xv[i], kw[i]);      // tile il+1 (loads of the previous iteration)
             }
-            if (t + 2 < t1) fill_rows(i1 * TP + nrows4, TP);               // new rows of tile t+2
+            PAIR_PH(9);
+            const int body2 = il + 2 < ntl ? (il + 2) * TP + q.halo : q.halo;                     // (past the end: any rows -- keeps six loads behind the DMAs)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mm[i] = tbl[(body2 + ra + 64 * i) & (WG_TBL - 1)];
+            if (il + 3 < ntl) fill_rows((il + 2) * TP + nrows4, TP);       // new rows of tile il+3
             PAIR_PH(10);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PAIR_PH(11);
-            __syncthreads();                                                // (tile)
+            if (il + 1 < ntl) dma_rows(il * TP + nrows4, TP);              // the 128 rows tile il+1 does not share with tile il
+            PAIR_PH(8);
+            __builtin_amdgcn_sched_barrier(0);                             // program order = issue order: the six loads below stay BEHIND the DMAs
+#pragma unroll
+            for (int i = 0; i < 2; ++i) eff_fetch(mm[i], gv[i], xv[i], kw[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (tile) DMAs landed, eff tile and table written
             PAIR_PH(12);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (g.dbias != nullptr) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bred[ra * 32 + ec * 8 + j] = bsum[j];
