@@ -719,8 +719,12 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                     const int row = row0 + rg * 4, rr = row + rsub;       // row0 multiple of 4: the group stays inside the ring
                     const char* src = mrow[i] >= 0 ? reinterpret_cast<const char*>(YA + (long)mrow[i] * 128) + ((slot ^ (rr & 15)) << 4)
                                                    : zeros + (slot << 4);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(smem + (row & (WG_RING - 1)) * 256), 16, 0, 0);
+                    // the DMA as inline assembly: behind the builtin the compiler orders every later LDS access of this wave (eff tile,
+                    // table) behind vmcnt(0) -- it cannot know they touch other rows -- which would put the DMAs last in the iteration with
+                    // their latency exposed at the barrier.  The waits that matter are placed by hand (vmcnt(6) in front of the barrier).
+                    const unsigned lds = __builtin_amdgcn_readfirstlane(
+                        (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)(smem + (row & (WG_RING - 1)) * 256)));
+                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(src) : "memory");      // (m0 is not allocatable: nothing else in this kernel uses it)
                 }
             }
         };
@@ -748,10 +752,11 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         int cur = 0;
         PAIR_T0();
         for (int il = 0; il < ntl; ++il, cur ^= 1) {
-            // LDS accesses first, global_load_lds last: the compiler orders every LDS access after a DMA behind vmcnt(0) (the DMA writes LDS).
-            // The explicit vmcnt(0) here is free (the six loads of the previous iteration landed a tile ago) and tells the compiler's
-            // scoreboard so on every path -- without it a vmcnt(0) appears between the DMAs and the loads below.
+            // the six slice loads of the previous iteration landed a tile ago: this wait is free, and it tells the compiler's scoreboard
+            // that their registers are ready, so that nothing below waits on the vmcnt counter behind the DMAs
             __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (il + 1 < ntl) dma_rows(il * TP + nrows4, TP);              // the 128 rows tile il+1 does not share with tile il: requested first,
+            PAIR_PH(8);                                                    // they travel under the eff tile and the table work
             if (il + 1 < ntl) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) eff_store(cur ^ 1, i, mm[i], gv[i], xv[i], kw[i]);      // tile il+1 (loads of the previous iteration)
@@ -762,8 +767,6 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
             for (int i = 0; i < 2; ++i) mm[i] = tbl[(body2 + ra + 64 * i) & (WG_TBL - 1)];
             if (il + 3 < ntl) fill_rows((il + 2) * TP + nrows4, TP);       // new rows of tile il+3
             PAIR_PH(10);
-            if (il + 1 < ntl) dma_rows(il * TP + nrows4, TP);              // the 128 rows tile il+1 does not share with tile il
-            PAIR_PH(8);
             __builtin_amdgcn_sched_barrier(0);                             // program order = issue order: the six loads below stay BEHIND the DMAs
 #pragma unroll
             for (int i = 0; i < 2; ++i) eff_fetch(mm[i], gv[i], xv[i], kw[i]);
@@ -1193,6 +1196,212 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Third data-gradient kernel (the one the dense layers of blocks 1-3 run): consecutive tiles per workgroup, the eff image in a ring
+// of 512 rows, one barrier per tile.  k_conv3x3_dgrad2_bf16 rebuilds the whole (128 + 2 halo)-row eff image per tile (2.1x the rows
+// at W = 69, each with its dropout flags and BatchNorm mean terms) and walks ten barriers per tile -- fp32 C tile exchange between the
+// four waves, pass by pass -- which its ablations put at half of its time ("other": 177 of 358 us).  Here:
+//   * 512 threads = 8 waves: wave (cs, ph) owns output channels [32 cs, +32) for positions [64 ph, +64) of the tile; its 18 weight
+//     fragments stay in registers; two waves per SIMD, so one wave's epilogue runs under the other's MFMAs;
+//   * every eff row is built ONCE, as one of the 128 new rows of the next tile: thread -> (row, 16-B chunk), slice loads requested
+//     two tiles ahead, keep bits or hash;
+//   * the epilogue is wave-private: the wave's 32 x 32 fp32 tile goes through its own LDS patch (no workgroup barrier), a lane then
+//     owns (row, 8 channels): Y load (requested before the MFMAs), PReLU / BatchNorm backward, 16-B store, fp32 running sums.
+// Row space as in the weight-gradient kernel: row 0 = padded position t0 * TP - halo, ring slot = row & 511, table entry = row & 1023.
+constexpr int DG_RING = 512, DG_TBL = 1024, DG_CP = 36;
+__global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradArgs g, int n_img, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const EffSrc& e = g.e;
+    const PadGeom q(n_img, g.H, g.W);
+    const int nrows = q.rows();
+    constexpr int o_tbl = DG_RING * 64, o_tab = o_tbl + DG_TBL * 4, o_cw = o_tab + 448 * 4;
+    int* tbl = reinterpret_cast<int*>(smem + o_tbl);
+    float* tab = reinterpret_cast<float*>(smem + o_tab);        // sc, sh, sl of norm2 [3][128]; P, Q of the slice [2][32]
+    double* red = reinterpret_cast<double*>(smem + o_cw);       // [8][32][3] after the last tile (aliases the C patches)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cs = wave & 3, ph = wave >> 2;
+    float* Cw = reinterpret_cast<float*>(smem + o_cw) + wave * 32 * DG_CP;      // this wave's [32][DG_CP] fp32 patch
+    const int r = lane & 31, h = lane >> 5;
+    const float invWp = 1.0f / q.Wp, invHp = 1.0f / q.Hp;
+    const bf16* __restrict__ G = reinterpret_cast<const bf16*>(e.G);
+    const bf16* __restrict__ D = reinterpret_cast<const bf16*>(e.X);
+    const bf16* __restrict__ Y = reinterpret_cast<const bf16*>(g.Xin);
+    const char* __restrict__ zeros = reinterpret_cast<const char*>(g.zeros);
+    bf16* __restrict__ DU = reinterpret_cast<bf16*>(g.Gout);
+    const uint32_t* __restrict__ KM = e.keep;
+    const int nb = gridDim.x, per = ntiles / nb, rem = ntiles % nb;
+    const int t0 = blockIdx.x * per + min((int)blockIdx.x, rem), ntl = per + ((int)blockIdx.x < rem ? 1 : 0);
+    const int g_org = t0 * TP - q.halo;
+    const bool drop = e.drop_p > 0.f;
+    const uint32_t dkey = drop_key(e.seed, e.stream_id);
+    const float dinv = 1.f / (1.f - e.drop_p);
+
+    const bf16* __restrict__ Wf = reinterpret_cast<const bf16*>(g.Wfrag) + ((long)cs * 18 * 64 + lane) * 8;
+    bf16x8_t bw[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + i * 512);
+    if (tid < 128) { tab[tid] = g.sc[tid]; tab[128 + tid] = g.sh[tid]; tab[256 + tid] = g.sl[tid]; }
+    if (tid < 32) { tab[384 + tid] = e.P[tid]; tab[416 + tid] = e.Q[tid]; }
+
+    // eff role of a thread: chunk ec of one row per 128-row batch
+    const int ec = tid & 3, er = tid >> 2;
+    auto fill_rows = [&](int row0, int n) {
+        for (int i = tid; i < n; i += 512) tbl[(row0 + i) & (DG_TBL - 1)] = pix_of(q, g_org + row0 + i, invWp, invHp);
+    };
+    auto eff_fetch = [&](int m, u16x8& gv, u16x8& xv, uint32_t& kw) {
+        const long o = (long)(m >= 0 ? m : 0);
+        gv = *reinterpret_cast<const u16x8*>(G + o * e.ldg + e.c_off + ec * 8);
+        xv = *reinterpret_cast<const u16x8*>(D + o * e.ldx + e.c_off + ec * 8);
+        kw = *(KM != nullptr ? KM + o : reinterpret_cast<const uint32_t*>(zeros));
+    };
+    auto eff_store = [&](int row, int m, const u16x8& gv, const u16x8& xv, uint32_t kw) {      // eff = (G + P*x + Q) * dropout; 0 on padding rows
+        u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (m >= 0) {
+            const float4 p0 = *reinterpret_cast<const float4*>(tab + 384 + ec * 8), p1 = *reinterpret_cast<const float4*>(tab + 388 + ec * 8);
+            const float4 q0 = *reinterpret_cast<const float4*>(tab + 416 + ec * 8), q1 = *reinterpret_cast<const float4*>(tab + 420 + ec * 8);
+            const float cP[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w}, cQ[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const uint32_t kb = kw >> (ec * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
+                if (drop) v *= KM != nullptr ? (((kb >> j) & 1u) ? dinv : 0.f)
+                                             : drop_pick(drop_bits32(dkey, m, ec * 8 + j, e.N), m, e.drop_p);      // (pixels * N < 2^32: launcher)
+                o[j] = f2bf(v);
+            }
+        }
+        *reinterpret_cast<u16x8*>(smem + off64(row & (DG_RING - 1), ec)) = o;
+    };
+
+    if (ntl > 0) fill_rows(0, nrows + min(ntl - 1, 2) * TP);                // tile 0's rows, the new rows of tiles 1 and 2
+    __syncthreads();
+    if (ntl > 0) {
+        for (int row = er; row < nrows; row += 128) {                       // tile 0: all its rows
+            u16x8 g0, x0; uint32_t k0;
+            const int m = tbl[row & (DG_TBL - 1)];
+            eff_fetch(m, g0, x0, k0);
+            eff_store(row, m, g0, x0, k0);
+        }
+    }
+    u16x8 gv, xv;
+    uint32_t kw = 0;
+    int mm = -1;
+    if (ntl > 1) { mm = tbl[(nrows + er) & (DG_TBL - 1)]; eff_fetch(mm, gv, xv, kw); }       // tile 1's new rows
+    else { gv = u16x8{0, 0, 0, 0, 0, 0, 0, 0}; xv = gv; }
+    __syncthreads();
+
+    // epilogue role of a lane in its wave's 32 x 32 patch: rows el and el + 16, channel chunk e4
+    const int e4 = lane & 3, el = lane >> 2;
+    float st1[8], st2[8], st3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { st1[j] = 0.f; st2[j] = 0.f; st3[j] = 0.f; }
+
+    for (int il = 0; il < ntl; ++il) {
+        const int trow = il * TP;                                            // first image row of this tile
+        // ---- next tiles: eff rows of tile il+1 into the ring, slice loads of tile il+2, table of tile il+3 ----
+        if (il + 1 < ntl) eff_store(trow + nrows + er, mm, gv, xv, kw);
+        if (il + 2 < ntl) { mm = tbl[(trow + TP + nrows + er) & (DG_TBL - 1)]; eff_fetch(mm, gv, xv, kw); }
+        if (il + 3 < ntl) fill_rows(trow + 2 * TP + nrows, TP);
+        // ---- this tile: Y rows of the wave's 64 positions, requested ahead of the MFMAs ----
+        int em[2][2];
+        u16x8 yv[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                em[mt][i] = tbl[(trow + q.halo + ph * 64 + mt * 32 + el + 16 * i) & (DG_TBL - 1)];
+                const long o = (long)(em[mt][i] >= 0 ? em[mt][i] : 0);
+                yv[mt][i] = *reinterpret_cast<const u16x8*>(Y + o * g.ldxin + cs * 32 + e4 * 8);
+            }
+        f32x16 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[mt][k] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int base = trow + q.halo - ((tap / 3 - 1) * q.Wp + (tap % 3 - 1)) + ph * 64 + r;      // source position = p - shift(tap)
+            if (tap % 3 == 0) __builtin_amdgcn_sched_barrier(0);           // (keeps the address arithmetic of later taps out of the early ones' registers)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(smem + off64((base + mt * 32) & (DG_RING - 1), 2 * ks + h));
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[tap * 2 + ks], acc[mt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: u = sc*y + sh ; dU = dA * prelu'(u) ; DU = sc*dU ; sums (dU, dU*y, dA*min(u,0)) per channel ----
+        float esc[8], esh[8], esl[8];                                        // norm2's table of this lane's 8 channels (re-read per tile: 24 registers
+#pragma unroll                                                               // the MFMA phase needs more)
+        for (int j4 = 0; j4 < 2; ++j4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(tab + cs * 32 + e4 * 8 + j4 * 4);
+            const float4 b4 = *reinterpret_cast<const float4*>(tab + 128 + cs * 32 + e4 * 8 + j4 * 4);
+            const float4 c4 = *reinterpret_cast<const float4*>(tab + 256 + cs * 32 + e4 * 8 + j4 * 4);
+            esc[j4 * 4] = a4.x; esc[j4 * 4 + 1] = a4.y; esc[j4 * 4 + 2] = a4.z; esc[j4 * 4 + 3] = a4.w;
+            esh[j4 * 4] = b4.x; esh[j4 * 4 + 1] = b4.y; esh[j4 * 4 + 2] = b4.z; esh[j4 * 4 + 3] = b4.w;
+            esl[j4 * 4] = c4.x; esl[j4 * 4 + 1] = c4.y; esl[j4 * 4 + 2] = c4.z; esl[j4 * 4 + 3] = c4.w;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Cw[((k & 3) + 8 * (k >> 2) + 4 * h) * DG_CP + r] = acc[mt][k];
+            // (the same wave reads what it wrote: LDS operations of a wave execute in order, no barrier)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = em[mt][i];
+                const float4 ca = *reinterpret_cast<const float4*>(Cw + (el + 16 * i) * DG_CP + e4 * 8);
+                const float4 cc = *reinterpret_cast<const float4*>(Cw + (el + 16 * i) * DG_CP + e4 * 8 + 4);
+                const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cc.x, cc.y, cc.z, cc.w};
+                u16x8 o;
+                const bool ok = m >= 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = bf2f(yv[mt][i][j]);
+                    const float u = fmaf(y, esc[j], esh[j]);
+                    const float c = ok ? cv[j] : 0.f;
+                    const float du = u > 0.f ? c : esl[j] * c;
+                    st1[j] += du; st2[j] = fmaf(du, y, st2[j]); st3[j] += u > 0.f ? 0.f : c * u;
+                    o[j] = f2bf(esc[j] * du);
+                }
+                if (ok) *reinterpret_cast<u16x8*>(DU + (long)m * g.ldgo + cs * 32 + e4 * 8) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tile il+1's rows and the table entries are in place
+    }
+    // per-channel sums: lanes with equal e4 hold the same 8 channels (fold lane bits 2..5), the two position halves through LDS
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double d1 = (double)st1[j], d2 = (double)st2[j], d3 = (double)st3[j];
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) { d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o); }
+        if (lane < 4) {
+            double* p = red + ((wave * 32) + e4 * 8 + j) * 3;
+            p[0] = d1; p[1] = d2; p[2] = d3;
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int c_cs = tid >> 5, c_in = tid & 31;
+        double a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const double* p = red + (((hh * 4 + c_cs) * 32) + c_in) * 3;
+            a += p[0]; b += p[1]; c += p[2];
+        }
+        double* p = g.part + ((long)blockIdx.x * g.N + tid) * 3;
+        p[0] = a; p[1] = b; p[2] = c;
+    }
+}
+size_t dgrad3_smem() { return size_t(DG_RING) * 64 + DG_TBL * 4 + 448 * 4 + 8 * 32 * DG_CP * 4; }
+bool dgrad3_ok(const ConvDgradArgs& a, const PadGeom& q) {
+    [[maybe_unused]] static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
+    return a.zeros != nullptr && a.e.N == 32 && (a.e.c_off & 7) == 0 && q.rows() + TP + 8 <= DG_RING && !TCVN_DBG_BIT(dbg, 4096) &&
+           (reinterpret_cast<uintptr_t>(a.e.G) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.e.X) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.Xin) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.Gout) & 15) == 0;      // TCVN_DBG=4096: the two-workgroup kernel
+}
+
 size_t dgrad2_smem(const PadGeom& q) { const size_t nr = (q.rows() + 15) & ~15; return 3 * nr * 64 + 2 * nr * 4 + 32 * 132 * 4 + 448 * 4 + ((nr + 63) & ~size_t(63)) * 4; }
 size_t dgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return r4 * 68 + 128 * 24 + 64 * 132 * 4; }
 int tile_grid2(long ntiles) {           // two workgroups per CU
@@ -1338,14 +1547,24 @@ bool conv3x3_dgrad_tile_ok(const ConvDgradArgs& a) {
 }
 int conv3x3_dgrad_tile_nblk(const ConvDgradArgs& a) {
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
-    return tile_grid2(q.tiles());
+    return dgrad3_ok(a, q) ? tile_grid(q.tiles()) : tile_grid2(q.tiles());      // one 512-thread workgroup per CU, or two of 256
 }
 int conv3x3_dgrad_tile(const ConvDgradArgs& a, hipStream_t st) {
     const int n_img = a.M / (a.H * a.W);
     const PadGeom q(n_img, a.H, a.W);
     const int ntiles = (int)q.tiles();
-    const int nb = tile_grid2(ntiles);
     ProfScope ps("k_conv3x3_dgrad_bf16", 2.0 * a.M * (double)a.N * 9 * a.e.N, (double)a.M * 2.0 * (2 * a.e.N + 2 * a.N), st);   // (G, x) slices in; Y in, DU out
+    if (dgrad3_ok(a, q)) {                 // consecutive tiles, eff ring, wave-private epilogue
+        static bool attr3 = false;
+        if (!attr3) {
+            TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_dgrad3_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr3 = true;
+        }
+        hipLaunchKernelGGL(k_conv3x3_dgrad3_bf16, dim3(tile_grid(ntiles)), dim3(512), dgrad3_smem(), st, a, n_img, ntiles);
+        TCVN_LAUNCH_CHECK();
+        return 0;
+    }
+    const int nb = tile_grid2(ntiles);
     // pipelined variant: needs the concat slice 16-B aligned for the LDS-DMA and all 32 channels present
     if (a.zeros != nullptr && a.e.N == 32 && (a.e.c_off & 7) == 0 && dgrad2_smem(q) <= 80 * 1024 &&
         (reinterpret_cast<uintptr_t>(a.e.G) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.e.X) & 15) == 0) {
