@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
     const EffSrc& e = g.e;
     const PadGeom q(n_img, g.H, g.W);
     const int nrows = q.rows();
-    constexpr int o_tbl = DG_RING * 64, o_tab = o_tbl + DG_TBL * 4, o_cw = o_tab + 448 * 4;
+    constexpr int o_tbl = DG_RING * 64, o_tab = o_tbl + DG_TBL * 4, o_cw = o_tab + 448 * 4, o_w = o_cw + 8 * 32 * DG_CP * 4;
     int* tbl = reinterpret_cast<int*>(smem + o_tbl);
     float* tab = reinterpret_cast<float*>(smem + o_tab);        // sc, sh, sl of norm2 [3][128]; P, Q of the slice [2][32]
     double* red = reinterpret_cast<double*>(smem + o_cw);       // [8][32][3] after the last tile (aliases the C patches)
@@ -1237,10 +1237,14 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
     const uint32_t dkey = drop_key(e.seed, e.stream_id);
     const float dinv = 1.f / (1.f - e.drop_p);
 
-    const bf16* __restrict__ Wf = reinterpret_cast<const bf16*>(g.Wfrag) + ((long)cs * 18 * 64 + lane) * 8;
-    bf16x8_t bw[18];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) bw[i] = *reinterpret_cast<const bf16x8_t*>(Wf + i * 512);
+    // the 4 x 18 weight fragments (72 KB) live in LDS: in registers (72 per lane) they push the kernel past the 256 registers two waves
+    // per SIMD leave each, next to the accumulators, the Y rows in flight and the running sums
+    {
+        const u16x8* __restrict__ wsrc = reinterpret_cast<const u16x8*>(g.Wfrag);
+        u16x8* wdst = reinterpret_cast<u16x8*>(smem + o_w);
+        for (int i = tid; i < 4 * 18 * 64; i += 512) wdst[i] = wsrc[i];
+    }
+    const char* wl = smem + o_w + (cs * 18 * 64 + lane) * 16;
     if (tid < 128) { tab[tid] = g.sc[tid]; tab[128 + tid] = g.sh[tid]; tab[256 + tid] = g.sl[tid]; }
     if (tid < 32) { tab[384 + tid] = e.P[tid]; tab[416 + tid] = e.Q[tid]; }
 
@@ -1295,6 +1299,19 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
     float st1[8], st2[8], st3[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { st1[j] = 0.f; st2[j] = 0.f; st3[j] = 0.f; }
+    // Y rows of the wave's two 32-position passes: slot mt is reloaded with the NEXT tile's rows as soon as this tile's pass mt has
+    // consumed it, so a request has a whole tile to arrive (requested at the top of its own tile it had the MFMA phase only: ~1 us
+    // against 2-4 us of HBM latency under load, and the first version of this kernel ran 45 % slower than the kernel it replaces)
+    u16x8 yq[2][2];
+    auto y_fetch = [&](int tile_row, int mt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = tbl[(tile_row + q.halo + ph * 64 + mt * 32 + el + 16 * i) & (DG_TBL - 1)];
+            const long o = (long)(m >= 0 ? m : 0);
+            yq[mt][i] = *reinterpret_cast<const u16x8*>(Y + o * g.ldxin + cs * 32 + e4 * 8);
+        }
+    };
+    if (ntl > 0) { y_fetch(0, 0); y_fetch(0, 1); }
 
     for (int il = 0; il < ntl; ++il) {
         const int trow = il * TP;                                            // first image row of this tile
@@ -1302,17 +1319,6 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
         if (il + 1 < ntl) eff_store(trow + nrows + er, mm, gv, xv, kw);
         if (il + 2 < ntl) { mm = tbl[(trow + TP + nrows + er) & (DG_TBL - 1)]; eff_fetch(mm, gv, xv, kw); }
         if (il + 3 < ntl) fill_rows(trow + 2 * TP + nrows, TP);
-        // ---- this tile: Y rows of the wave's 64 positions, requested ahead of the MFMAs ----
-        int em[2][2];
-        u16x8 yv[2][2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                em[mt][i] = tbl[(trow + q.halo + ph * 64 + mt * 32 + el + 16 * i) & (DG_TBL - 1)];
-                const long o = (long)(em[mt][i] >= 0 ? em[mt][i] : 0);
-                yv[mt][i] = *reinterpret_cast<const u16x8*>(Y + o * g.ldxin + cs * 32 + e4 * 8);
-            }
         f32x16 acc[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -1321,13 +1327,13 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int base = trow + q.halo - ((tap / 3 - 1) * q.Wp + (tap % 3 - 1)) + ph * 64 + r;      // source position = p - shift(tap)
-            if (tap % 3 == 0) __builtin_amdgcn_sched_barrier(0);           // (keeps the address arithmetic of later taps out of the early ones' registers)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wl + (tap * 2 + ks) * 1024);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(smem + off64((base + mt * 32) & (DG_RING - 1), 2 * ks + h));
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[tap * 2 + ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mt], 0, 0, 0);
                 }
             }
         }
@@ -1349,7 +1355,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
             // (the same wave reads what it wrote: LDS operations of a wave execute in order, no barrier)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int m = em[mt][i];
+                const int m = tbl[(trow + q.halo + ph * 64 + mt * 32 + el + 16 * i) & (DG_TBL - 1)];
                 const float4 ca = *reinterpret_cast<const float4*>(Cw + (el + 16 * i) * DG_CP + e4 * 8);
                 const float4 cc = *reinterpret_cast<const float4*>(Cw + (el + 16 * i) * DG_CP + e4 * 8 + 4);
                 const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cc.x, cc.y, cc.z, cc.w};
@@ -1357,7 +1363,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
                 const bool ok = m >= 0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float y = bf2f(yv[mt][i][j]);
+                    const float y = bf2f(yq[mt][i][j]);
                     const float u = fmaf(y, esc[j], esh[j]);
                     const float c = ok ? cv[j] : 0.f;
                     const float du = u > 0.f ? c : esl[j] * c;
@@ -1366,6 +1372,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
                 }
                 if (ok) *reinterpret_cast<u16x8*>(DU + (long)m * g.ldgo + cs * 32 + e4 * 8) = o;
             }
+            if (il + 1 < ntl) y_fetch(trow + TP, mt);                        // this slot's rows of the next tile
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tile il+1's rows and the table entries are in place
     }
@@ -1394,7 +1401,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
         p[0] = a; p[1] = b; p[2] = c;
     }
 }
-size_t dgrad3_smem() { return size_t(DG_RING) * 64 + DG_TBL * 4 + 448 * 4 + 8 * 32 * DG_CP * 4; }
+size_t dgrad3_smem() { return size_t(DG_RING) * 64 + DG_TBL * 4 + 448 * 4 + 8 * 32 * DG_CP * 4 + 4 * 18 * 1024; }
 bool dgrad3_ok(const ConvDgradArgs& a, const PadGeom& q) {
     [[maybe_unused]] static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
     return a.zeros != nullptr && a.e.N == 32 && (a.e.c_off & 7) == 0 && q.rows() + TP + 8 <= DG_RING && !TCVN_DBG_BIT(dbg, 4096) &&

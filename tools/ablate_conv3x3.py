@@ -34,7 +34,7 @@ print("RESULT " + json.dumps(res))
 """
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 rows = {}
-for dbg in (0, 8, 4, 2):
+for dbg in (0, 4096):
     code = f"ROOT = {ROOT!r}\nNMAPS = {n}\n" + CHILD
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TCVN_DBG=str(dbg)), capture_output=True, text=True, timeout=600)
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
