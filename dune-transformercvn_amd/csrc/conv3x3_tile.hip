@@ -1401,10 +1401,14 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
         p[0] = a; p[1] = b; p[2] = c;
     }
 }
+static long cu_tiles() { return 256; }      // workgroups of a full persistent grid (one per CU)
 size_t dgrad3_smem() { return size_t(DG_RING) * 64 + DG_TBL * 4 + 448 * 4 + 8 * 32 * DG_CP * 4 + 4 * 18 * 1024; }
 bool dgrad3_ok(const ConvDgradArgs& a, const PadGeom& q) {
     [[maybe_unused]] static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
+    // from 8 tiles per workgroup on: below that its prologue (72 KB of weights into LDS, the whole first eff image) costs more than the
+    // ring saves (block 3, 816 tiles: 37 us against 32 us for the two-workgroup kernel; block 2, 3 600 tiles: 94 against 102)
     return a.zeros != nullptr && a.e.N == 32 && (a.e.c_off & 7) == 0 && q.rows() + TP + 8 <= DG_RING && !TCVN_DBG_BIT(dbg, 4096) &&
+           (q.tiles() >= 8 * cu_tiles() || TCVN_DBG_BIT(dbg, 8192)) &&                 // TCVN_DBG=8192 (validation build): at any size
            (reinterpret_cast<uintptr_t>(a.e.G) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.e.X) & 15) == 0 &&
            (reinterpret_cast<uintptr_t>(a.Xin) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.Gout) & 15) == 0;      // TCVN_DBG=4096: the two-workgroup kernel
 }
