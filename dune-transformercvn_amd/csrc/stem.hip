@@ -5,6 +5,7 @@
 //     touches ~12 output pixels per hit instead of contracting 147 taps for every one of the 28 000 output pixels
 //     (~1.7 GFLOP instead of 135 GFLOP per 288 maps).
 #include <cstdlib>
+#include <type_traits>
 #include "tcvn_ops.h"
 #include "prof.h"
 
@@ -103,29 +104,52 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad_sparse(const StemWgradArg
 #pragma unroll
     for (int t = 0; t < 49; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; }
     const long gw = (long)blockIdx.x * 4 + (tid >> 6), nw = (long)gridDim.x * 4;
+    // the coordinates of the NEXT hit are requested while this one is processed (a hit is a chain of dependent L2 round trips:
+    // coordinates -> pixel value / gradient rows; with the first link prefetched a wave pays one per hit instead of two to three)
+    int c_im = -1, c_y = 0, c_x = 0;
+    if (gw < a.nnz) { c_im = a.coords[gw * 3]; c_y = a.coords[gw * 3 + 1]; c_x = a.coords[gw * 3 + 2]; }
     for (long hit = gw; hit < a.nnz; hit += nw) {
-        const int im = __builtin_amdgcn_readfirstlane(a.coords[hit * 3]);
-        const int y = __builtin_amdgcn_readfirstlane(a.coords[hit * 3 + 1]);
-        const int x = __builtin_amdgcn_readfirstlane(a.coords[hit * 3 + 2]);
+        const int im = __builtin_amdgcn_readfirstlane(c_im);
+        const int y = __builtin_amdgcn_readfirstlane(c_y);
+        const int x = __builtin_amdgcn_readfirstlane(c_x);
+        if (hit + nw < a.nnz) { c_im = a.coords[(hit + nw) * 3]; c_y = a.coords[(hit + nw) * 3 + 1]; c_x = a.coords[(hit + nw) * 3 + 2]; }
         if (im < 0 || im >= a.n_img || y < 0 || y >= a.H || x < 0 || x >= a.W) continue;
         const T* px = img + (((long)im * a.H + y) * a.W + x) * a.Cpix;
         float v[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = c < a.Cpix ? to_f<T>(px[c]) : 0.f;
+        // The taps that see this hit have ky = (y+3) mod 2 (+2, +4, +6) and kx likewise: 9-16 of the 49.  One code copy per parity pair
+        // keeps the accumulator indices static AND lets all <= 32 gradient-row loads of the hit be requested before the first use (the
+        // tap-by-tap loop with its parity tests waited for every tap's two loads in turn: ~16 L2 round trips per hit).
+        auto taps = [&](auto pyc, auto pxc) {
+            constexpr int PY = decltype(pyc)::value, PX = decltype(pxc)::value;
+            constexpr int NY = PY ? 3 : 4, NX = PX ? 3 : 4;
+            float gq[NY][NX], xq[NY][NX];
+            bool okq[NY][NX];
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            const int ty = y + 3 - ky;
-            if ((ty & 1) || ty < 0 || (ty >> 1) >= a.Hc) continue;
+            for (int iy = 0; iy < NY; ++iy)
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                const int tx = x + 3 - kx;
-                if ((tx & 1) || tx < 0 || (tx >> 1) >= a.Wc) continue;
-                const long p = ((long)im * a.Hc + (ty >> 1)) * a.Wc + (tx >> 1);
-                const float eff = nok ? to_f<T>(G[p * a.e.ldg + n]) + pn * to_f<T>(X[p * a.e.ldx + n]) + qn : 0.f;
+                for (int ix = 0; ix < NX; ++ix) {
+                    const int oy = (y + 3 - (PY + 2 * iy)) >> 1, ox = (x + 3 - (PX + 2 * ix)) >> 1;       // (y+3-ky even by construction)
+                    okq[iy][ix] = ((unsigned)oy < (unsigned)a.Hc) & ((unsigned)ox < (unsigned)a.Wc) & nok;
+                    const long p = okq[iy][ix] ? ((long)im * a.Hc + oy) * a.Wc + ox : 0;                  // clamped: unconditional loads
+                    gq[iy][ix] = to_f<T>(G[p * a.e.ldg + (nok ? n : 0)]);
+                    xq[iy][ix] = to_f<T>(X[p * a.e.ldx + (nok ? n : 0)]);
+                }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[ky * 7 + kx][c] = fmaf(v[c], eff, acc[ky * 7 + kx][c]);
-            }
-        }
+            for (int iy = 0; iy < NY; ++iy)
+#pragma unroll
+                for (int ix = 0; ix < NX; ++ix) {
+                    const float eff = okq[iy][ix] ? gq[iy][ix] + pn * xq[iy][ix] + qn : 0.f;
+                    constexpr int dummy = 0; (void)dummy;
+                    const int t = (PY + 2 * iy) * 7 + (PX + 2 * ix);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[t][c] = fmaf(v[c], eff, acc[t][c]);
+                }
+        };
+        const int pyr = (y + 3) & 1, pxr = (x + 3) & 1;                       // wave-uniform
+        if (pyr == 0) { if (pxr == 0) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); else taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); }
+        else { if (pxr == 0) taps(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); else taps(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); }
     }
 #pragma unroll
     for (int t = 0; t < 49; ++t)
@@ -417,6 +441,159 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd_bf16(const ConvFwdArgs g, i
         }
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// conv0 forward, second version.  Same tile, patch and contraction order as k_stem_fwd_bf16; what changed is everything around the
+// 28 MFMAs, which was ~1 100 instructions per wave and tile (the kernel wrote its 1 GB at 1.36 TB/s, issue-bound):
+//   * the MFMA operands are swapped -- weights are the A operand, the patch fragment the B operand -- so a lane holds, for ITS pixel,
+//     4 consecutive channels per accumulator group: one v_cvt_pk pair and one 8-B LDS write per group (8 writes per lane and tile
+//     instead of 32 two-byte writes), no per-element bounds branch (one validity flag per lane and tile);
+//   * the 28 weight fragments live in LDS (28 KB), which frees 112 registers for the per-lane statistics (a lane accumulates the 64
+//     sums of its 32 channels over all its tiles; the 32-lane fold happens once, at the end) and the batched patch loads;
+//   * patch loads are unconditional from clamped addresses + select, 32-bit tile arithmetic.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_stem_fwd2_bf16(const ConvFwdArgs g, int n_img, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) unsigned short patch[2][ST_PR * ST_PW * 4];
+    __shared__ __attribute__((aligned(16))) unsigned short ctile[ST_TH * ST_TW * ST_CP];
+    __shared__ __attribute__((aligned(16))) unsigned short wl[2 * 14 * 64 * 8];          // [ct][s][lane] weight fragments
+    __shared__ double red[4][64][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const bf16* __restrict__ img = reinterpret_cast<const bf16*>(g.A);
+    const bf16* __restrict__ Wk = reinterpret_cast<const bf16*>(g.Wk);          // [64][Kp], k = (ky*7 + kx)*3 + c
+    bf16* __restrict__ Out = reinterpret_cast<bf16*>(g.Out);
+    const int Hin = g.Hin, Win = g.Win, Ho = g.H, Wo = g.W;
+    const unsigned ntiles = (unsigned)n_img * tiles_x * tiles_y;
+
+    // weight fragments: lane (r, h) of channel tile ct holds k' = 16 s + 8 h + i for output channel ct*32 + r
+    for (int f = wave; f < 28; f += 4) {
+        const int ct = f / 14, sstep = f - ct * 14;
+        u16x8 w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kp = 16 * sstep + 8 * h + i, ky = kp >> 5, kx = (kp & 31) >> 2, c = kp & 3;
+            w[i] = (kx < 7 && c < 3) ? Wk[(long)(ct * 32 + r) * g.Kp + (ky * 7 + kx) * 3 + c] : (bf16)0;
+        }
+        *reinterpret_cast<u16x8*>(&wl[(f * 64 + lane) * 8]) = w;
+    }
+    // this lane's 32 channels: ct*32 + (k&3) + 8*(k>>2) + 4*h
+    float bias[2][16], f1[2][16], f2[2][16];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { bias[ct][k] = g.bias[ct * 32 + (k & 3) + 8 * (k >> 2) + 4 * h]; f1[ct][k] = 0.f; f2[ct][k] = 0.f; }
+    for (int i = tid; i < 2 * ST_PR * ST_PW * 4; i += 256) (&patch[0][0])[i] = 0;      // 4th channel + pitch padding stay zero
+
+    // patch staging: element e of patch row pr is input (iy0 + pr, ix0 + e/3, channel e%3); 21 x 111 elements, <= 10 per thread
+    constexpr int NE = ST_PR * 37 * 3, PER = (NE + 255) / 256;
+    int e_pr[PER], e_pc[PER];                                    // patch row; pixel * 4 + channel
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + 256 * k;
+        const int pr = i / 111, e = i - pr * 111, px = e / 3, c = e - px * 3;
+        e_pr[k] = i < NE ? pr : -100000;                        // out-of-range elements fail the row test below
+        e_pc[k] = px * 4 + c;
+    }
+    auto load_patch = [&](unsigned tile, unsigned short (&v)[PER]) {
+        const unsigned trow = tile / tiles_x;
+        const int tx = (int)(tile - trow * tiles_x), ty = (int)(trow % tiles_y);
+        const long n = trow / tiles_y;
+        const int iy0 = 2 * ty * ST_TH - 3, ix0 = 2 * tx * ST_TW - 3;
+        const bf16* base = img + ((n * Hin + iy0) * (long)Win + ix0) * 3;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int px = e_pc[k] >> 2, c = e_pc[k] & 3;
+            const int iy = iy0 + e_pr[k], ix = ix0 + px;
+            const bool ok = ((unsigned)iy < (unsigned)Hin) & ((unsigned)ix < (unsigned)Win);
+            const unsigned short x = *(ok ? base + (e_pr[k] * Win + px) * 3 + c : img);      // unconditional load, clamped address
+            v[k] = ok ? x : (unsigned short)0;
+        }
+    };
+    auto store_patch = [&](int buf, const unsigned short (&v)[PER]) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (e_pr[k] >= 0) patch[buf][e_pr[k] * (ST_PW * 4) + e_pc[k]] = v[k];
+    };
+
+    unsigned short pv[PER];
+    unsigned tile = blockIdx.x;
+    __syncthreads();
+    if (tile < ntiles) { load_patch(tile, pv); store_patch(0, pv); }
+    __syncthreads();
+    int cur = 0;
+    const int oy_l = 2 * wave + (r >> 4), ox_l = r & 15;          // this lane's pixel of the tile
+    for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+        const bool more = tile + gridDim.x < ntiles;
+        if (more) load_patch(tile + gridDim.x, pv);                // next patch travels under the MFMAs
+        f32x16 acc[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[ct][k] = 0.f;
+        const unsigned short* pb = &patch[cur][0];
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int gq = 2 * s + h, ky = gq >> 2, q4 = gq & 3;
+            const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(pb + ((2 * oy_l + ky) * ST_PW + 2 * ox_l + 2 * q4) * 4);
+            const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(&wl[(s * 64 + lane) * 8]);
+            const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(&wl[((14 + s) * 64 + lane) * 8]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, b, acc[1], 0, 0, 0);
+        }
+        const unsigned trow = tile / tiles_x;
+        const int tx = (int)(tile - trow * tiles_x), ty = (int)(trow % tiles_y);
+        const long n = trow / tiles_y;
+        const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+        const float vm = ((oy0 + oy_l < Ho) & (ox0 + ox_l < Wo)) ? 1.f : 0.f;             // this lane's pixel is inside the map
+        unsigned short* cp = &ctile[(oy_l * ST_TW + ox_l) * ST_CP + 4 * h];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                u16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = gq * 4 + j;
+                    o[j] = f2bf(acc[ct][k] + bias[ct][k]);
+                    const float x = bf2f(o[j]) * vm;
+                    f1[ct][k] += x; f2[ct][k] = fmaf(x, x, f2[ct][k]);
+                }
+                *reinterpret_cast<u16x4*>(cp + ct * 32 + gq * 8) = o;
+            }
+        if (more) store_patch(cur ^ 1, pv);
+        __syncthreads();
+        // 128 pixels x 128 B: 4 chunks of 16 B per thread
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + 256 * k, p = idx >> 3, c8 = idx & 7;
+            const int py = p >> 4, px = p & 15;
+            if ((oy0 + py < Ho) & (ox0 + px < Wo))
+                *reinterpret_cast<u16x8*>(Out + ((n * Ho + oy0 + py) * (long)Wo + ox0 + px) * g.ldo + c8 * 8) =
+                    *reinterpret_cast<const u16x8*>(&ctile[p * ST_CP + c8 * 8]);
+        }
+        __syncthreads();
+    }
+    if (g.part != nullptr) {
+        // fold the 32 pixel lanes of each half wave; lanes 0 and 32 then hold the wave's sums of their 32 channels
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                double a = (double)f1[ct][k], b = (double)f2[ct][k];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+                if (r == 0) { const int c = ct * 32 + (k & 3) + 8 * (k >> 2) + 4 * h; red[wave][c][0] = a; red[wave][c][1] = b; }
+            }
+        __syncthreads();
+        if (tid < 64) {
+            double a = 0, b = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += red[w][tid][0]; b += red[w][tid][1]; }
+            g.part[((long)blockIdx.x * 64 + tid) * 2] = a;
+            g.part[((long)blockIdx.x * 64 + tid) * 2 + 1] = b;
+        }
+    }
+}
+
 }  // namespace
 
 int pool0_bwd_vec_grid(int n_img, int Hin, int Win) {
@@ -472,7 +649,9 @@ int stem_fwd_nblk(const ConvFwdArgs& a) {
 int stem_fwd_bf16(const ConvFwdArgs& a, hipStream_t st) {
     const int n_img = a.M / (a.H * a.W);
     ProfScope ps("k_stem_fwd_bf16", 2.0 * a.M * (double)a.N * a.K, (double)a.M * 2.0 * (a.N + 4.0 * a.C), st);
-    hipLaunchKernelGGL(k_stem_fwd_bf16, dim3(stem_fwd_nblk(a)), dim3(256), 0, st, a, n_img, cdiv(a.W, ST_TW), cdiv(a.H, ST_TH));
+    [[maybe_unused]] static const bool old_kernel = TCVN_KNOB_SET("TCVN_STEM_FWD_V1");         // validation build: the first version
+    if (old_kernel) hipLaunchKernelGGL(k_stem_fwd_bf16, dim3(stem_fwd_nblk(a)), dim3(256), 0, st, a, n_img, cdiv(a.W, ST_TW), cdiv(a.H, ST_TH));
+    else hipLaunchKernelGGL(k_stem_fwd2_bf16, dim3(stem_fwd_nblk(a)), dim3(256), 0, st, a, n_img, cdiv(a.W, ST_TW), cdiv(a.H, ST_TH));
     TCVN_LAUNCH_CHECK();
     return 0;
 }
