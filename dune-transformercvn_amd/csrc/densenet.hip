@@ -54,7 +54,10 @@ DenseNetPlan::DenseNetPlan(const tcvn_densenet_cfg& c) : cfg(c) {
     s_a0 = add_slot(f + ".relu0.weight", ch, TCVN_SLOT_PARAM);
     for (int b = 0; b < cfg.n_blocks; ++b) {
         BlockGeom bg;
-        bg.H = h; bg.W = w; bg.C0 = ch; bg.L = cfg.layers[b]; bg.Ctot = ch + bg.L * g; bg.ld = (int)round_up(bg.Ctot, 8);
+        bg.H = h; bg.W = w; bg.C0 = ch; bg.L = cfg.layers[b]; bg.Ctot = ch + bg.L * g; bg.ldp = (int)round_up(bg.Ctot, 8);
+        // bf16 rows start on 128-B lines: the kernels read and write channel PREFIXES of these rows (1x1 input, its gradient's
+        // read-modify-write); with a 320-B pitch (160 channels) every second prefix straddles one line more than it has to
+        bg.ld = cfg.mode == MODE_BF16 ? (int)round_up(bg.Ctot, 64) : bg.ldp;
         for (int l = 0; l < bg.L; ++l) {
             LayerSlots ls;
             const int cin = ch + l * g;
@@ -155,7 +158,7 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
         }
         L.XA.push_back(xas);
         const bool tfast = bg.has_trans && fastt_ok(bg.Ctot);
-        L.XP.push_back(tfast ? b.take((long)n * (bg.H / 2) * (bg.W / 2) * bg.ld * esz) : -1);   // row stride bg.ld, zero padded
+        L.XP.push_back(tfast ? b.take((long)n * (bg.H / 2) * (bg.W / 2) * bg.ldp * esz) : -1);   // row stride bg.ldp, zero padded
         L.bstatD.push_back(b.take((long)bg.ld * 16));
         max_part = std::max(max_part, 512L * std::max(mid, bg.Ctot) * 16);   // every conv launcher uses <= 512 workgroups
         maxY = std::max(maxY, M * mid);
@@ -526,13 +529,13 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             const long Mn = (long)n * nb.H * nb.W;
             const bool fastt = L.XP[bi] >= 0;
             if (fastt) {
-                ActPoolArgs ap{D, bg.ld, n, bg.H, bg.W, bg.Ctot, t.sc, t.sh, data[bg.ta], ws + L.XP[bi], bg.ld};
+                ActPoolArgs ap{D, bg.ld, n, bg.H, bg.W, bg.Ctot, t.sc, t.sh, data[bg.ta], ws + L.XP[bi], bg.ldp};
                 if ((rc = act_pool_bf16(ap, st))) return rc;
             }
             if (fastt) {
                 const WkEntry& ef = wk_find(bg.tw, 0, 1);
                 GemmNtArgs ga{};
-                ga.epi = EPI_FWD; ga.A = ws + L.XP[bi]; ga.lda = bg.ld; ga.K = bg.ld; ga.M = Mn; ga.N = bg.Ctot / 2;
+                ga.epi = EPI_FWD; ga.A = ws + L.XP[bi]; ga.lda = bg.ldp; ga.K = bg.ldp; ga.M = Mn; ga.N = bg.Ctot / 2;
                 ga.Wfrag = ws + L.wk + ef.off; ga.Kp = ef.Kp; ga.zeros = ws + L.zeros; ga.bias = data[bg.tb];
                 ga.Out = ws + L.D[bi + 1]; ga.ldo = nb.ld; ga.n_off = 0; ga.part = train ? part : nullptr; ga.nblk = gemm_nt_nblk(ga);
                 if ((rc = gemm_nt_bf16(ga, "k_gemm_nt_bf16<fwdtrans>", st))) return rc;

@@ -208,7 +208,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 SlabJob bias_job{};
                 EffMatArgs em{e, Mn, ws + L.ey, Nt8, grad[bg.tb], reinterpret_cast<float*>(ws + L.slab + kSlabGemmBytes), &bias_job};
                 if ((rc = eff_materialize_bf16(em, st))) return rc;
-                GemmTnArgs ga{ws + L.ey, Nt8, Nt8, ws + L.XP[bi], bg.ld, bg.ld, Mn, gw_of(bg.tw), ef.Kp, ws + L.zeros,
+                GemmTnArgs ga{ws + L.ey, Nt8, Nt8, ws + L.XP[bi], bg.ldp, bg.ldp, Mn, gw_of(bg.tw), ef.Kp, ws + L.zeros,
                               reinterpret_cast<float*>(ws + L.slab), kSlabGemmBytes, Nt, bias_job};
                 if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<transition>", st))) return rc;
             } else if ((rc = conv_wgrad(w, st))) return rc;

@@ -12,7 +12,8 @@ struct Slot { std::string name; long numel; int kind; };
 struct BnSlots { int w = -1, b = -1, rm = -1, rv = -1, nbt = -1, C = 0, id = -1; };
 struct LayerSlots { BnSlots n1, n2; int a1, w1, b1, a2, w2, b2, cin; };
 struct BlockGeom {
-    int H, W, C0, L, Ctot, ld;
+    int H, W, C0, L, Ctot, ld;        // ld: channel pitch of the concat / gradient buffers (bf16: a multiple of 64 = whole 128-B lines per row)
+    int ldp;                          // channel pitch of the pooled transition input XP (Ctot rounded up to 8: also its GEMM's K extent)
     std::vector<LayerSlots> layers;
     bool has_trans = false;
     BnSlots tn; int ta = -1, tw = -1, tb = -1;
