@@ -728,6 +728,30 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                 }
             }
         };
+        // With the eff rows materialised by the data-gradient kernel (e.ey): a tile's 128 rows x 64 B arrive by DMA like the image rows,
+        // 16 rows per wave instruction (lane = 4 * row + chunk); the helper then only adds up the bias gradient from the landed tile.
+        const bf16* __restrict__ EYs = reinterpret_cast<const bf16*>(e.ey);
+        auto dma_eff = [&](int row0, int buf) {                            // row0: first body row of the tile
+            const int rsub = lane >> 2, chunk = lane & 3;
+            int mr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mr[i] = tbl[(row0 + (w4 + 4 * i) * 16 + rsub) & (WG_TBL - 1)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* src = mr[i] >= 0 ? reinterpret_cast<const char*>(EYs + (long)mr[i] * 32 + chunk * 8) : zeros + chunk * 16;
+                const unsigned lds = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)(smem + eff_off + buf * TP * 64 + (w4 + 4 * i) * 1024)));
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(src) : "memory");
+            }
+        };
+        auto bias_from_tile = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u16x8 v = *reinterpret_cast<const u16x8*>(smem + eff_off + buf * TP * 64 + (ra + 64 * i) * 64 + ec * 16);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum[j] += bf2f(v[j]);
+            }
+        };
         // Pipeline of the helper role, iteration i (tile t0 + i is being multiplied): eff tile of tile i+1 from the slice rows requested
         // one iteration earlier (a tile time ago: they have arrived), DMA of tile i+1's new image rows, slice loads of tile i+2,
         // table entries of tile i+3's new rows.  The barrier waits for the DMAs only -- vmcnt(6): the six slice loads behind them stay in
@@ -740,10 +764,13 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         int mm[2] = {-1, -1};
         if (ntl > 0) {
             dma_rows(0, nrows4);
+            if (EYs != nullptr) dma_eff(q.halo, 0);
+            else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { u16x8 g0, x0; uint32_t k0; const int m = eff_load(q.halo, i, g0, x0, k0); eff_store(0, i, m, g0, x0, k0); }
+                for (int i = 0; i < 2; ++i) { u16x8 g0, x0; uint32_t k0; const int m = eff_load(q.halo, i, g0, x0, k0); eff_store(0, i, m, g0, x0, k0); }
+            }
         }
-        if (ntl > 1) {
+        if (ntl > 1 && EYs == nullptr) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) mm[i] = eff_load(TP + q.halo, i, gv[i], xv[i], kw[i]);
         }
@@ -751,6 +778,21 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         __syncthreads();                                                    // (2)
         int cur = 0;
         PAIR_T0();
+        if (EYs != nullptr) {
+            for (int il = 0; il < ntl; ++il, cur ^= 1) {
+                if (il + 1 < ntl) {
+                    dma_rows(il * TP + nrows4, TP);                        // image: the 128 rows tile il+1 does not share with tile il
+                    dma_eff((il + 1) * TP + q.halo, cur ^ 1);              // its eff rows
+                }
+                PAIR_PH(8);
+                bias_from_tile(cur);
+                PAIR_PH(9);
+                if (il + 3 < ntl) fill_rows((il + 2) * TP + nrows4, TP);   // new rows of tile il+3
+                PAIR_PH(10);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (tile)
+                PAIR_PH(12);
+            }
+        } else
         for (int il = 0; il < ntl; ++il, cur ^= 1) {
             // the six slice loads of the previous iteration landed a tile ago: this wait is free, and it tells the compiler's scoreboard
             // that their registers are ready, so that nothing below waits on the vmcnt counter behind the DMAs
@@ -1230,6 +1272,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
     const char* __restrict__ zeros = reinterpret_cast<const char*>(g.zeros);
     bf16* __restrict__ DU = reinterpret_cast<bf16*>(g.Gout);
     const uint32_t* __restrict__ KM = e.keep;
+    bf16* __restrict__ EY = reinterpret_cast<bf16*>(g.ey_out);
     const int nb = gridDim.x, per = ntiles / nb, rem = ntiles % nb;
     const int t0 = blockIdx.x * per + min((int)blockIdx.x, rem), ntl = per + ((int)blockIdx.x < rem ? 1 : 0);
     const int g_org = t0 * TP - q.halo;
@@ -1275,6 +1318,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
             }
         }
         *reinterpret_cast<u16x8*>(smem + off64(row & (DG_RING - 1), ec)) = o;
+        if (EY != nullptr && m >= 0) *reinterpret_cast<u16x8*>(EY + (long)m * 32 + ec * 8) = o;      // the weight gradient's operand, built once
     };
 
     if (ntl > 0) fill_rows(0, nrows + min(ntl - 1, 2) * TP);                // tile 0's rows, the new rows of tiles 1 and 2
@@ -1555,6 +1599,10 @@ bool conv3x3_dgrad_tile_ok(const ConvDgradArgs& a) {
     if ((a.e.ldg & 7) || (a.e.ldx & 7) || (a.e.c_off & 1) || a.M % (a.H * a.W) != 0) return false;
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);
     return q.gtot < (1L << 24) && (long)a.M * a.e.N < (1L << 32);
+}
+bool conv3x3_dgrad_writes_ey(const ConvDgradArgs& a) {
+    if (a.ey_out == nullptr || !conv3x3_dgrad_tile_ok(a)) return false;
+    return dgrad3_ok(a, PadGeom(a.M / (a.H * a.W), a.H, a.W));
 }
 int conv3x3_dgrad_tile_nblk(const ConvDgradArgs& a) {
     const PadGeom q(a.M / (a.H * a.W), a.H, a.W);

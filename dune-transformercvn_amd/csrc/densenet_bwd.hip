@@ -57,6 +57,13 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     L.bpart = b.take(bpart);
     L.dF = b.take((long)n * Cf * 4);
     L.dZ = b.take((long)n * cfg.out_dim * 4);
+    L.EY3.clear();                                 // per dense layer: the 3x3 output gradient's eff rows, data gradient -> weight gradient
+    for (const auto& bg : blocks) {
+        std::vector<long> eys;
+        if (cfg.mode == MODE_BF16 && cfg.growth == 32)
+            for (int l = 0; l < bg.L; ++l) eys.push_back(b.take((long)n * bg.H * bg.W * 32 * esz));
+        L.EY3.push_back(eys);
+    }
     L.total = b.off;
 }
 
@@ -245,10 +252,24 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             EffSrc e2{G, bg.ld, D, bg.ld, ls.cin, g, P + ls.cin, Q + ls.cin, cfg.dropout, seed, sid};
             if (bi < (int)keep_valid.size() && l < (int)keep_valid[bi].size() && keep_valid[bi][l] && !L.KM[bi].empty())
                 e2.keep = reinterpret_cast<const uint32_t*>(ws + L.KM[bi][l]);      // keep words of this layer's forward (else: the hash)
-            {   // conv2 (3x3) weight gradient
+            bool ey_valid = false;
+            {   // conv2 data gradient -> DU (= sc2 * dU2) + norm2 partials (+ the eff rows for the weight gradient below)
+                const WkEntry& et = wk_find(ls.w2, 1);
+                ConvDgradArgs d{};
+                d.mode = mode; d.dmode = DG_3X3; d.e = e2; d.M = (int)M; d.N = mid; d.Kp = et.Kp; d.H = bg.H; d.W = bg.W;
+                d.Wt = ws + L.wk + et.off; d.Xin = Y; d.ldxin = mid; d.sc = sc_of(ls.n2); d.sh = sh_of(ls.n2); d.sl = data[ls.a2];
+                d.Gout = DU; d.ldgo = mid; d.accumulate = 0; d.part = part;
+                d.Wfrag = wk_frag(ws, L, ls.w2, 1); d.zeros = ws + L.zeros;
+                if (fast3x3 && !L.EY3[bi].empty()) { d.ey_out = ws + L.EY3[bi][l]; ey_valid = conv3x3_dgrad_writes_ey(d); if (!ey_valid) d.ey_out = nullptr; }
+                d.nblk = conv_dgrad_nblk(d);
+                if ((rc = conv_dgrad(d, st))) return rc;
+                if ((rc = bwd_link(ls.n2, d.nblk, reinterpret_cast<const double*>(ws + L.bstatY[bi][l]), M, PY, QY, 0, ls.a2))) return rc;
+            }
+            {   // conv2 (3x3) weight gradient: beside the rest of this layer's data-gradient chain
                 const WkEntry& ef = wk_find(ls.w2, 0);
                 ConvWgradArgs w{};
                 w.mode = mode; w.e = e2; w.dWk = gw_of(ls.w2); w.dbias = grad[ls.b2];
+                if (ey_valid) w.e.ey = ws + L.EY3[bi][l];
                 w.fa.mode = mode; w.fa.amode = A_3X3; w.fa.A = Y; w.fa.lda = mid; w.fa.M = (int)M; w.fa.N = g; w.fa.K = 9 * mid;
                 w.fa.Kp = ef.Kp; w.fa.C = mid; w.fa.H = bg.H; w.fa.W = bg.W;
                 w.fa.sc = sc_of(ls.n2); w.fa.sh = sh_of(ls.n2); w.fa.sl = data[ls.a2];
@@ -257,23 +278,12 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                     w.slab = reinterpret_cast<float*>(ws + L.slab); w.slab_bytes = kSlabBytes;
                 }
                 const bool par = side_on && L.XA[bi][l] >= 0;
-                if (par) {                    // G slice, its (P, Q) and the materialised YA are final: fork
+                if (par) {                    // G slice, its (P, Q), the materialised YA and the eff rows are final: fork
                     TCVN_CHECK(hipEventRecord(ev_fork_a, st));
                     TCVN_CHECK(hipStreamWaitEvent(side_st, ev_fork_a, 0));
                     side_busy = true;
                 }
                 if ((rc = conv_wgrad(w, par ? side_st : st))) return rc;
-            }
-            {   // conv2 data gradient -> DU (= sc2 * dU2) + norm2 partials
-                const WkEntry& et = wk_find(ls.w2, 1);
-                ConvDgradArgs d{};
-                d.mode = mode; d.dmode = DG_3X3; d.e = e2; d.M = (int)M; d.N = mid; d.Kp = et.Kp; d.H = bg.H; d.W = bg.W;
-                d.Wt = ws + L.wk + et.off; d.Xin = Y; d.ldxin = mid; d.sc = sc_of(ls.n2); d.sh = sh_of(ls.n2); d.sl = data[ls.a2];
-                d.Gout = DU; d.ldgo = mid; d.accumulate = 0; d.part = part;
-                d.Wfrag = wk_frag(ws, L, ls.w2, 1); d.zeros = ws + L.zeros;
-                d.nblk = conv_dgrad_nblk(d);
-                if ((rc = conv_dgrad(d, st))) return rc;
-                if ((rc = bwd_link(ls.n2, d.nblk, reinterpret_cast<const double*>(ws + L.bstatY[bi][l]), M, PY, QY, 0, ls.a2))) return rc;
             }
             EffSrc e1{DU, mid, Y, mid, 0, mid, PY, QY, 0.f, 0, 0};
             {   // conv1 (1x1) weight gradient

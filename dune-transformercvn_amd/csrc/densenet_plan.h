@@ -24,6 +24,7 @@ struct Layout {
     long img, c0, bstat0, part, tabs, F, Z, head_stat, wk, fwd_end, total;
     std::vector<long> D, bstatD;
     std::vector<std::vector<long>> Y, bstatY, YA;     // YA: activated bf16 copies of Y (bf16 mode)
+    std::vector<std::vector<long>> EY3;               // bf16 mode: [pixels][32] eff rows of a layer's 3x3 output gradient (data gradient -> weight gradient)
     std::vector<std::vector<long>> KM;                // bf16 mode with dropout: one keep word per pixel and dense layer (3x3 output dropout)
     long zeros, ey, ey2, slab;
     long sidx;                           // sparse-stem bucket index (stem_sparse.hip), -1 when the plan cannot use it

@@ -107,6 +107,8 @@ struct EffSrc {
     float drop_p; uint64_t seed; uint32_t stream_id;
     const uint32_t* keep;            // optional (bf16 tile kernels): bit n of keep[m] = dropout keep flag of channel n of pixel m, as the
                                      // forward kernel drew it (ConvFwdArgs::keep_out) -- a bit test instead of the hash per element
+    const void* ey;                  // optional (3x3 weight gradient, N == 32): the eff rows themselves, [pixels][32] bf16, as the data-gradient
+                                     // kernel of the same layer built and stored them (ConvDgradArgs::ey_out): fetched by LDS-DMA, no arithmetic
 };
 
 enum DMode { DG_1X1 = 0, DG_1X1_POOL = 1, DG_3X3 = 2 };
@@ -124,8 +126,10 @@ struct ConvDgradArgs {
     double* part; int nblk;        // [nblk][N][3]
     const void* Wfrag;             // optional: Wt in MFMA fragment order (bf16 padded-tile 3x3 kernel)
     const void* zeros;             // optional: >= 64 B of zeros (LDS-DMA source of padding rows)
+    void* ey_out;                  // optional [M][32] bf16: the consecutive-tile 3x3 kernel stores every eff row it builds (for the weight gradient)
 };
 int conv_dgrad(const ConvDgradArgs& a, hipStream_t st);
+bool conv3x3_dgrad_writes_ey(const ConvDgradArgs& a);   // true when conv_dgrad(a) runs the kernel that fills ey_out
 int conv_dgrad_nblk(const ConvDgradArgs& a);      // grid.x (rows of `part`) conv_dgrad will use (<= 512)
 bool conv3x3_dgrad_tile_ok(const ConvDgradArgs& a);
 int conv3x3_dgrad_tile_nblk(const ConvDgradArgs& a);
