@@ -289,6 +289,41 @@ result = dict(out=out, taps=taps, grads=grads)
     assert e_out < 5e-3 and e_tap < 1e-2 and e_w0 < 0.2
 
 
+def test_stem_forward_v2_matches_v1():
+    """k_stem_fwd2_bf16 (operands swapped, weights in LDS, per-lane statistics) against the first conv0 kernel (TCVN_STEM_FWD_V1 on
+    the validation build, separate process): the same products in the same k order, so the conv0 output must be BIT-identical; the
+    statistics are summed in a different order, so everything behind norm0 agrees to bf16-rounding level."""
+    cfg, over, batch, g = _mid_case()
+    cfg = train_cfg(over)
+    sd = O.fill_state(cfg, int(g["weight_seed"]))
+    n_img = int(batch[7].sum())
+    eng, data, _ = _engine(cfg, sd, mode=1)
+    out = torch.empty(n_img, eng.out_dim, device="cuda")
+    eng.forward(batch[5].cuda(), batch[6].cuda(), n_img, out, train=True, seed=1)
+    torch.cuda.synchronize()
+    c0, d1 = eng.tap("conv0").clone().cpu(), eng.tap("dense1").float().cpu()
+    from variant_utils import run_on_debug_build
+    ref = run_on_debug_build("""
+import test_densenet_gpu as T
+from oracle import tcvn_oracle as O
+from golden_utils import train_cfg
+cfg, over, batch, g = T._mid_case()
+cfg = train_cfg(over)
+sd = O.fill_state(cfg, int(g['weight_seed']))
+n_img = int(batch[7].sum())
+eng, data, _ = T._engine(cfg, sd, mode=1)
+out = torch.empty(n_img, eng.out_dim, device='cuda')
+eng.forward(batch[5].cuda(), batch[6].cuda(), n_img, out, train=True, seed=1)
+torch.cuda.synchronize()
+result = dict(c0=eng.tap('conv0').clone().cpu(), d1=eng.tap('dense1').float().cpu(), out=out.cpu())
+""", dict(TCVN_STEM_FWD_V1="1"))
+    assert torch.equal(c0.view(torch.int16), ref["c0"].view(torch.int16))
+    e_d1 = ((d1 - ref["d1"]).norm() / ref["d1"].norm()).item()
+    e_out = ((out.cpu() - ref["out"]).norm() / ref["out"].norm()).item()
+    print("stem v2 vs v1: conv0 bit-identical; dense1", e_d1, "embedding", e_out)
+    assert e_d1 < 5e-3 and e_out < 2e-2
+
+
 def test_bf16_consecutive_tile_dgrad_matches_two_workgroup_kernel():
     """k_conv3x3_dgrad3_bf16 (consecutive tiles, eff ring, wave-private epilogue, dropout keep words; the product takes it from 8 tiles
     per workgroup on, TCVN_DBG=8192 on the validation build forces it at this test's size, separate process) against
