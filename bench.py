@@ -465,6 +465,22 @@ def main():
         if roof:
             out["roofline"] = roof
             out["kernels"] = kernels[:8]
+        if not args.ragged_inference and world == 1:
+            # beside the fwd+bwd figure BASELINE.json's metric names: the same step followed by the optimizer update the reference's
+            # train.py performs (AdamW over two groups + gradient clipping; here one fused launch over the flat arenas)
+            try:
+                optimizer = model.configure_optimizers()[0][0]
+                for _ in range(2):
+                    step(); optimizer.step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    step(); optimizer.step()
+                torch.cuda.synchronize()
+                out["with_optimizer_ms_per_step"] = round(1000 * (time.perf_counter() - t0) / 3, 3)
+                out["with_optimizer_note"] = f"fwd+loss+bwd + {type(optimizer).__name__}.step(), 3 steps"
+            except Exception as ex:                # a reported extra, never a reason to lose the line
+                note(f"optimizer-step timing skipped: {ex}")
         if args.precision == "bf16" and world == 1 and not args.no_fp32 and not args.sdxl and not args.ragged_inference:
             note("fp32 parity mode (1 warm-up + 2 steps) ...")
             del model, rt
