@@ -368,6 +368,10 @@ class _Ctx:
         # "<densenet prefix>:dense<b>.<l>" [n,g,H,W], "<densenet prefix>:out" [n,out], "<linear block prefix>" [rows,D],
         # "<encoder layer prefix>:attn" [B*H,S,S], ":sa" / ":ffn_act" / ":ffn" [S,B,D], "decoder.<i>" [T*B,width].
         self.mask_provider = mask_provider
+        # checkpoint=True: the stem and every dense layer / transition of the DenseNets run under
+        # torch.utils.checkpoint (recomputed in backward: same arithmetic, same gradients), which keeps the
+        # 288-map train step of BASELINE config 2 under ~15 GB instead of ~60 GB of saved activations.
+        self.checkpoint = False
         self.taps: Dict[str, Tensor] = {}
         self.new_running: Dict[str, Tensor] = {}
 
@@ -405,32 +409,58 @@ def _dropout(x: Tensor, ctx: _Ctx, site: str = "") -> Tensor:
     return F.dropout(x, ctx.dropout, True)
 
 
+def _segment(ctx: _Ctx, fn, x: Tensor) -> Tensor:
+    """Run one DenseNet segment, under activation checkpointing when ctx.checkpoint is set (memory only: the
+    recomputation repeats the same CPU arithmetic; dropout sites replay the generator state / the mask provider)."""
+    if ctx.checkpoint and ctx.training and torch.is_grad_enabled():
+        from torch.utils.checkpoint import checkpoint
+        return checkpoint(fn, x, use_reentrant=False)
+    return fn(x)
+
+
 def densenet_forward(sd, prefix: str, cfg, x: Tensor, ctx: _Ctx) -> Tensor:
     """layers/dense_net.py:8-45 (Bottleneck), 48-75 (DenseBlock), 78-94 (Transition), 97-167 (DenseNet)."""
     f = prefix + ".features"
-    x = F.conv2d(x, sd[f + ".conv0.weight"], sd[f + ".conv0.bias"], stride=2, padding=3)
-    ctx.taps[prefix + ":conv0"] = x
-    x = _prelu(_batch_norm(sd, f + ".norm0", x, ctx), sd[f + ".relu0.weight"])
-    x = F.avg_pool2d(x, kernel_size=3, stride=2)
+    keep_taps = not ctx.checkpoint                               # full-resolution taps would defeat the checkpointing
+
+    def stem(x):
+        x = F.conv2d(x, sd[f + ".conv0.weight"], sd[f + ".conv0.bias"], stride=2, padding=3)
+        if keep_taps:
+            ctx.taps[prefix + ":conv0"] = x
+        x = _prelu(_batch_norm(sd, f + ".norm0", x, ctx), sd[f + ".relu0.weight"])
+        return F.avg_pool2d(x, kernel_size=3, stride=2)
+
+    def dense_layer(p, tap):
+        def run(x):
+            y = _prelu(_batch_norm(sd, p + ".bottleneck_block.norm1", x, ctx), sd[p + ".bottleneck_block.relu1.weight"])
+            y = F.conv2d(y, sd[p + ".bottleneck_block.conv1.weight"], sd[p + ".bottleneck_block.conv1.bias"])
+            if tap is not None and keep_taps:
+                ctx.taps[tap] = y
+            y = _prelu(_batch_norm(sd, p + ".output_block.norm2", y, ctx), sd[p + ".output_block.relu2.weight"])
+            y = F.conv2d(y, sd[p + ".output_block.conv2.weight"], sd[p + ".output_block.conv2.bias"], padding=1)
+            return _dropout(y, ctx, tap_site[p])
+        return run
+
+    def transition(p):
+        def run(x):
+            x = _prelu(_batch_norm(sd, p + ".norm", x, ctx), sd[p + ".relu.weight"])
+            x = F.conv2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"])
+            return F.avg_pool2d(x, kernel_size=2, stride=2)
+        return run
+
+    tap_site: Dict[str, str] = {}
+    x = _segment(ctx, stem, x)
     ctx.taps[prefix + ":pool0"] = x
     nblocks = len(cfg.densenet_structure)
     for b, nl in enumerate(cfg.densenet_structure):
         for i in range(nl):
             p = f"{f}.dense{b + 1}.layers.{i}"
-            y = _prelu(_batch_norm(sd, p + ".bottleneck_block.norm1", x, ctx), sd[p + ".bottleneck_block.relu1.weight"])
-            y = F.conv2d(y, sd[p + ".bottleneck_block.conv1.weight"], sd[p + ".bottleneck_block.conv1.bias"])
-            if i == 0:
-                ctx.taps[f"{prefix}:dense{b + 1}.bottleneck0"] = y
-            y = _prelu(_batch_norm(sd, p + ".output_block.norm2", y, ctx), sd[p + ".output_block.relu2.weight"])
-            y = F.conv2d(y, sd[p + ".output_block.conv2.weight"], sd[p + ".output_block.conv2.bias"], padding=1)
-            y = _dropout(y, ctx, f"{prefix}:dense{b + 1}.{i}")
+            tap_site[p] = f"{prefix}:dense{b + 1}.{i}"
+            y = _segment(ctx, dense_layer(p, f"{prefix}:dense{b + 1}.bottleneck0" if i == 0 else None), x)
             x = torch.cat((x, y), dim=1)
         ctx.taps[f"{prefix}:dense{b + 1}"] = x
         if b != nblocks - 1:
-            p = f"{f}.transition{b + 1}"
-            x = _prelu(_batch_norm(sd, p + ".norm", x, ctx), sd[p + ".relu.weight"])
-            x = F.conv2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"])
-            x = F.avg_pool2d(x, kernel_size=2, stride=2)
+            x = _segment(ctx, transition(f"{f}.transition{b + 1}"), x)
             ctx.taps[f"{prefix}:transition{b + 1}"] = x
     x = _prelu(_batch_norm(sd, f + ".final_norm", x, ctx), sd[f + ".final_relu.weight"])
     x = x.mean(dim=(2, 3))                                      # AdaptiveAvgPool2d((1,1)) + Flatten
@@ -569,12 +599,13 @@ def decoders_forward(sd, cfg, hidden: Tensor, ctx: _Ctx) -> Tuple[Tensor, Tensor
 
 
 def forward(sd, cfg, batch8: Tuple[Tensor, ...], training: bool = False, apply_dropout: bool = False,
-            noise: Optional[Tuple[Tensor, Tensor]] = None, mask_provider=None):
+            noise: Optional[Tuple[Tensor, Tensor]] = None, mask_provider=None, checkpoint: bool = False):
     """trainers/neutrino_full_base_trainer.py:90-116 followed by networks/neutrino_full_base_network.py:166-188.
     Returns (event_logits [B,Ce], prong_logits [B,P,Cp], ctx)."""
     features, extra, event_coords, event_values, event_mask, prong_coords, prong_values, prong_mask = batch8
     dt = sd["network.event_decoder.hidden_layer.weight"].dtype
     ctx = _Ctx(training, cfg.dropout if apply_dropout else 0.0, mask_provider)
+    ctx.checkpoint = checkpoint
     features = features.clone().to(dt)
     extra = extra.clone().to(dt)
     if cfg.normalize_features:
@@ -588,12 +619,13 @@ def forward(sd, cfg, batch8: Tuple[Tensor, ...], training: bool = False, apply_d
     return ev, pr, ctx
 
 
-def shared_step(sd, cfg, batch10, training: bool, apply_dropout: bool = False, noise=None, mask_provider=None):
+def shared_step(sd, cfg, batch10, training: bool, apply_dropout: bool = False, noise=None, mask_provider=None,
+                checkpoint: bool = False):
     """trainers/neutrino_full_base_trainer.py:118-146 (truncate to the max real prong count)."""
     features, extra, ec, evv, em, pc, pv, pm, et, pt = batch10
     mp = int(pm.sum(1).max())
     ev, pr, ctx = forward(sd, cfg, (features[:, :mp].contiguous(), extra, ec, evv, em, pc, pv, pm[:, :mp].contiguous()),
-                          training, apply_dropout, noise, mask_provider)
+                          training, apply_dropout, noise, mask_provider, checkpoint)
     return et, pt[:, :mp].contiguous(), ev, pr, ctx
 
 
@@ -615,10 +647,15 @@ def training_loss(cfg, event_logits, prong_logits, event_targets, prong_targets)
     return s * el + (1.0 - s) * pl, el, pl
 
 
-def train_step(sd, cfg, batch10, apply_dropout: bool = False, noise=None, mask_provider=None):
+def train_step(sd, cfg, batch10, apply_dropout: bool = False, noise=None, mask_provider=None,
+               checkpoint: Optional[bool] = None):
     """One forward+backward of training_step; returns (losses, logits, grads dict, ctx).
     Gradients are taken w.r.t. every floating-point entry of `sd` that is not a BN running statistic
-    or a normalisation constant."""
+    or a normalisation constant.  `checkpoint` (default: on above 64 maps) recomputes the DenseNet segments in
+    backward instead of keeping their activations (BASELINE config 2 = 288 maps: ~60 GB without)."""
+    if checkpoint is None:
+        n_maps = int(batch10[7].sum()) + batch10[7].shape[0]
+        checkpoint = n_maps > 64
     skip = ("running_mean", "running_var", "num_batches_tracked")
     leaves = {}
     sd2 = {}
@@ -628,7 +665,7 @@ def train_step(sd, cfg, batch10, apply_dropout: bool = False, noise=None, mask_p
             sd2[k] = leaves[k]
         else:
             sd2[k] = v
-    et, pt, ev, pr, ctx = shared_step(sd2, cfg, batch10, True, apply_dropout, noise, mask_provider)
+    et, pt, ev, pr, ctx = shared_step(sd2, cfg, batch10, True, apply_dropout, noise, mask_provider, checkpoint)
     total, el, pl = training_loss(cfg, ev, pr, et, pt)
     names = list(leaves)
     gs = torch.autograd.grad(total, [leaves[n] for n in names], allow_unused=True)
