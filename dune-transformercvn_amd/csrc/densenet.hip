@@ -501,12 +501,23 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 a.Kp = e.Kp; a.C = mid; a.H = bg.H; a.W = bg.W; a.sc = t.sc; a.sh = t.sh; a.sl = data[ls.a2];
                 a.Wk = ws + L.wk + e.off; a.bias = data[ls.b2]; a.Out = D; a.ldo = bg.ld; a.n_off = ls.cin;
                 a.Wfrag = wk_frag(ws, L, ls.w2, 0);
-                if (mode == MODE_BF16) {       // materialise prelu(bn(Y)) once; the tile kernel stages it by LDS-DMA
-                    if (!fuse_ya) {
-                        ActArgs act{ws + L.Y[bi][l], mid, M, mid, t.sc, t.sh, data[ls.a2], ws + L.YA[bi][l], mid};
-                        if ((rc = act_bf16(act, st))) return rc;
+                if (act_fused.size() != blocks.size()) act_fused.assign(blocks.size(), std::vector<char>());
+                if ((int)act_fused[bi].size() != bg.L) act_fused[bi].assign(bg.L, 0);
+                act_fused[bi][l] = 0;
+                if (mode == MODE_BF16) {
+                    a.zeros = ws + L.zeros;
+                    // Round 4: norm2 + PReLU are applied INSIDE the 3x3 kernel (and inside the layer's weight-gradient kernel): the raw
+                    // bottleneck map is staged by LDS-DMA and the wave that fetched a row activates it in LDS once -- the activated copy YA
+                    // (256 B written + 256 B read per pixel and layer) and the k_act_bf16 launch over Y do not exist.  Bit-identical images.
+                    a.Aact = ws + L.Y[bi][l];
+                    if (!fuse_ya && conv3x3_act_fusable(a)) { a.act_fused = 1; act_fused[bi][l] = 1; }
+                    else {                     // materialise prelu(bn(Y)) once; the tile kernel stages it by LDS-DMA
+                        if (!fuse_ya) {
+                            ActArgs act{ws + L.Y[bi][l], mid, M, mid, t.sc, t.sh, data[ls.a2], ws + L.YA[bi][l], mid};
+                            if ((rc = act_bf16(act, st))) return rc;
+                        }
+                        a.Aact = ws + L.YA[bi][l];
                     }
-                    a.Aact = ws + L.YA[bi][l]; a.zeros = ws + L.zeros;
                 }
                 a.part = train ? part : nullptr;
                 a.drop_p = train ? cfg.dropout : 0.f; a.seed = seed; a.stream_id = (uint32_t)(bi * 64 + l + 1);
@@ -610,6 +621,7 @@ int DenseNetPlan::tap(int n, const char* name, long* off, int* tn, int* th, int*
         if (b < 0 || b >= (int)blocks.size() || l < 0 || l >= blocks[b].L) return -1;
         const bool xa = s[0] == 'x';
         if ((xa && (!xa_materialize() || L.XA[b].empty() || L.XA[b][l] < 0)) || (!xa && L.YA[b].empty())) return -1;
+        if (!xa && n == last_n && b < (int)act_fused.size() && l < (int)act_fused[b].size() && act_fused[b][l]) return -1;   // activated in LDS only
         *off = xa ? L.XA[b][l] : L.YA[b][l]; *th = blocks[b].H; *tw = blocks[b].W;
         *tc = xa ? blocks[b].layers[l].cin : cfg.bn_size * cfg.growth; *tld = xa ? (int)round_up(*tc, 8) : *tc;
         return 0;

@@ -274,7 +274,8 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 w.fa.Kp = ef.Kp; w.fa.C = mid; w.fa.H = bg.H; w.fa.W = bg.W;
                 w.fa.sc = sc_of(ls.n2); w.fa.sh = sh_of(ls.n2); w.fa.sl = data[ls.a2];
                 if (fast3x3) {
-                    w.nfast = 1; w.fa.Aact = ws + L.YA[bi][l]; w.fa.zeros = ws + L.zeros;
+                    const bool fused = bi < (int)act_fused.size() && l < (int)act_fused[bi].size() && act_fused[bi][l];
+                    w.nfast = 1; w.fa.Aact = fused ? Y : ws + L.YA[bi][l]; w.fa.act_fused = fused ? 1 : 0; w.fa.zeros = ws + L.zeros;
                     w.slab = reinterpret_cast<float*>(ws + L.slab); w.slab_bytes = kSlabBytes;
                 }
                 const bool par = side_on && L.XA[bi][l] >= 0;

@@ -30,9 +30,13 @@ struct ConvFwdArgs {
     double* part; int nblk;          // [nblk][N][2]; nblk = grid.x
     float drop_p; uint64_t seed; uint32_t stream_id;
     uint32_t* keep_out;              // optional [M]: the 3x3 pair kernel stores the keep flags of a pixel's N <= 32 channels as one word
+    int act_fused;                   // bf16 3x3 tile kernels (forward pair kernel, weight gradient): Aact is the RAW [pixels][128] map; the wave that
+                                     // fetched a row applies prelu(sc*x + sh, sl) to it in LDS, once, before any tap reads it -- no activated copy in HBM
 };
 int conv_fwd(const ConvFwdArgs& a, hipStream_t st);
 bool conv3x3_fwd_writes_keep(const ConvFwdArgs& a);   // true when conv_fwd(a) runs the kernel that fills keep_out
+bool conv3x3_act_fusable(const ConvFwdArgs& a);       // true when both the forward kernel conv_fwd(a) would run and the weight-gradient tile kernel of the
+                                                      // same layer can take the raw map (ConvFwdArgs::act_fused)
 int conv_fwd_grid(int M);            // number of M-blocks of the generic kernels for M rows (<= 512)
 int conv_fwd_nblk(const ConvFwdArgs& a);   // grid.x (== rows of `part`) conv_fwd will use for these arguments (<= 512)
 // bf16 3x3 fast path on padded LDS tiles (conv3x3_tile.hip)

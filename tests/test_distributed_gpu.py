@@ -68,3 +68,122 @@ def test_rccl_exchange_runs_on_hardware_at_world_size_one(case, precision):
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     print(p.stdout[-2000:], p.stderr[-3000:])
     assert p.returncode == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Two REAL ranks against the HIP backward (round-3 verdict, missing #6).  A one-rank collective is the identity, so the test above
+# cannot see an ordering mistake between the library's weight-gradient side stream, the event-embedder stream and the exchange.
+# Here two fresh processes share cuda:0 (a one-GPU box: no second device for RCCL, so the group runs on gloo -- the reducer's
+# SUM-then-scale branch, asynchronous work objects on CUDA tensors), start from DIFFERENT weights and draw DIFFERENT batches:
+#   * after enable_data_parallel() both ranks hold rank 0's parameters and buffers (sync_state);
+#   * each rank first takes one bf16 step WITHOUT the reducer (its local gradient), the two local gradients are averaged with a
+#     plain blocking all-reduce -> the expected arena;
+#   * then one step through the reducer (segments issued as backward finishes them, side streams on): every arena segment must be
+#     that mean, and the hooks must fire head -> event -> prong4 ... prong0.
+# ---------------------------------------------------------------------------------------------------------------------------------
+CHILD2 = r"""
+import os, sys, torch
+import torch.distributed as dist
+from oracle import tcvn_oracle as O
+from golden_utils import train_cfg
+from model_utils import build_trainer, to_device
+
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=2)
+over = dict(num_encoder_layers=2)                       # the tutorial DenseNets (5 blocks: 5 prong segments), bf16 engines
+cfg = train_cfg(over)                                   # dropout = noise = 0: the local step is reproducible
+sd = O.fill_state(cfg, 7 + 13 * rank)                   # DIFFERENT weights per rank
+batch = O.synthetic_batch([2, 3] if rank == 0 else [1, 2], 100 + rank, cfg)      # different batches, different prong counts
+dbatch = to_device(batch)
+
+model = build_trainer(cfg, sd, precision="bf16")
+model.train()
+rt = model.network.hip_runtime()
+rt.ensure_bound()
+before = rt.flat_param.clone()
+red = model.enable_data_parallel()
+assert red is not None and red.world == 2
+# (1) state: both ranks now hold rank 0's parameters / buffers
+ref_p, ref_b = rt.flat_param.clone(), rt.flat_buf.clone()
+dist.broadcast(ref_p, 0); dist.broadcast(ref_b, 0)
+assert torch.equal(ref_p, rt.flat_param) and torch.equal(ref_b, rt.flat_buf)
+if rank == 1:
+    assert not torch.equal(before, rt.flat_param), "rank 1 must have started from different weights"
+buf0 = rt.flat_buf.clone()
+
+def step(exchange, order):
+    rt.flat_buf.copy_(buf0)                             # the same BatchNorm running statistics in front of both steps
+    inner = red.on_ready
+    if exchange:
+        rt.grad_ready_hook = lambda tag: (order.append(tag), inner(tag))
+        model.on_train_batch_start(dbatch, 0)
+    else:
+        rt.grad_ready_hook = lambda tag: order.append(tag)          # same block-by-block backward schedule, no collective
+    rt.step = 5
+    rt.zero_grad()
+    loss = model.training_step(dbatch, 0)
+    loss.backward()
+    if exchange:
+        model.on_after_backward()
+    torch.cuda.synchronize()
+    return loss.item(), rt.flat_grad.clone()
+
+o_local, o_dp = [], []
+loss_local, g_local = step(False, o_local)
+expected = g_local.clone()
+dist.all_reduce(expected)                               # blocking SUM of the two LOCAL gradients
+expected /= 2
+loss_dp, g_dp = step(True, o_dp)
+n_blocks = len(cfg.densenet_structure)
+want = ["head", "event"] + [f"prong{i}" for i in range(n_blocks - 1, -1, -1)]
+assert o_dp == want and o_local == want, (o_dp, o_local)
+assert loss_dp == loss_local, (loss_dp, loss_local)
+worst = 0.0
+for tag, spans in red.plan.items():
+    e = torch.cat([expected[lo:hi] for lo, hi in spans])
+    m = torch.cat([g_dp[lo:hi] for lo, hi in spans])
+    l = torch.cat([g_local[lo:hi] for lo, hi in spans])
+    assert torch.isfinite(m).all() and e.norm() > 0, tag
+    err = ((m - e).norm() / e.norm()).item()
+    worst = max(worst, err)
+    assert err < 1e-6, (tag, err)
+    # and it is NOT the local gradient (the exchange really mixed two different ranks)
+    assert ((m - l).norm() / l.norm()).item() > 1e-3, tag
+# both ranks hold the same averaged arena
+other = g_dp.clone()
+dist.broadcast(other, 0)
+assert torch.equal(other, g_dp)
+dist.barrier()
+dist.destroy_process_group()
+print(f"rank {rank}: two-rank exchange against the HIP backward ok: segments {o_dp}, worst segment rel L2 vs mean of local gradients {worst:.2e}")
+"""
+
+
+def test_two_rank_exchange_against_the_hip_backward():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    code = f"import sys\nsys.path[:0] = {sys.path!r}\n" + CHILD2
+    procs, logs = [], []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        logs.append(tempfile.TemporaryFile(mode="w+"))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=logs[-1], stderr=subprocess.STDOUT, text=True))
+    import time
+    deadline = time.time() + 900
+    while any(p.poll() is None for p in procs) and time.time() < deadline:
+        if any(p.poll() not in (None, 0) for p in procs):          # one rank failed: the other would wait in a collective forever
+            break
+        time.sleep(0.5)
+    for p in procs:
+        if p.poll() is None:
+            p.kill()
+    for p, f in zip(procs, logs):
+        p.wait()
+        f.seek(0)
+        print(f.read()[-4000:])
+    assert all(p.returncode == 0 for p in procs)

@@ -91,15 +91,19 @@ def test_train_step_matches_reference(name):
 # The bf16 throughput mode is gated against the REFERENCE'S OWN bf16 behaviour on the same inputs and weights:
 # tests/golden/autocast_bf16_band.npz (oracle/make_autocast_band.py) holds the logits of the real reference module run under
 # torch.autocast(bfloat16) -- what `train.py -fp16` selects up to the half type -- on every golden case.  Its max-norm relative
-# logit error against the fp32 goldens is 0.9-2.7e-2 in eval mode and 0.02-0.74 in train mode (train mode on these batches is
-# degenerate for any 16-bit format: they hold 2-3 events, and BatchNorm1d over 2-3 rows maps the event embeddings to about -1/+1
-# whatever their size, so roundings of the embeddings move the logits a lot).  Measured here on MI355X: eval 1.3e-3 (small net) ...
-# 1.3e-2 (tutorial nets), train 0.02-0.34 -- inside the reference's band on every case.  Gates: eval <= 1.25 x the band and <= 2e-2
-# absolute; train <= 2 x the band: on these 2-3-event batches the train-mode figure is one draw of a chaotic quantity, for the reference
-# and for us -- a change of the conv0 statistics' summation ORDER (fp32 partial sums folded differently, last-bit differences) moved
-# tutorial_b2p4's prong figure from 0.17 to 0.39 with the eval figures unchanged to three digits; the band is a scale, not a bound.
-# The 32-event train step of test_fullsize_gpu.py (gate 1.25 x its band) is the meaningful train-mode bf16 check.
-BF16_EVAL_GATE, BAND_SLACK, TRAIN_BAND_SLACK = 2e-2, 1.25, 2.0
+# logit error against the fp32 goldens is 0.9-2.7e-2 in eval mode and 0.02-0.74 in train mode.  Eval gate: <= 1.25 x the band and
+# <= 2e-2 absolute (measured here: 1.3e-3 ... 1.3e-2).
+# TRAIN mode (round-3 verdict, weak #2): the train-mode LOGITS of these 2-3-event batches are one draw of a chaotic quantity for any
+# 16-bit format -- BatchNorm1d over 2-3 rows maps the embeddings to about -1/+1 whatever their size, so a last-bit change of a
+# summation order moved tutorial_b2p4's prong figure from 0.17 to 0.39 -- and an assert on them checks nothing.  The gate is therefore
+# put where the bf16 arithmetic ends and nothing chaotic has happened yet: the embedders' maps BEFORE the first BatchNorm1d -- the
+# pooled stem, every dense block, every transition and the condensed feature vector of both DenseNets (train-mode BatchNorm2d over
+# >= 10^4 positions per channel: well conditioned) -- against the reference's own fp32 train-mode taps in the goldens, max-norm
+# relative on the stored samples and on the (mean, std, max) summary.  Measured: 1.4e-3 ... 2.6e-2 (worst: dense blocks 4-5, after 27-30
+# bf16 layers; gate 4e-2).  The train-mode
+# logit figure stays in the printed line, next to the reference-under-autocast figure; the 32-event train step of
+# test_fullsize_gpu.py gates logits at config 2's real size, where BatchNorm1d sees 32 / 288 rows.
+BF16_EVAL_GATE, BAND_SLACK, BF16_TRAIN_TAP_GATE = 2e-2, 1.25, 4e-2
 
 
 def autocast_band(name):
@@ -108,10 +112,44 @@ def autocast_band(name):
     return d, d[f"{name}:logit_err"]
 
 
+def _train_tap_errors(model, cfg, g):
+    """max-norm relative error of the train-mode embedder taps of the last forward against the golden's reference taps."""
+    from golden_utils import tap_sample
+    rt = model.network.hip_runtime()
+    nb = len(cfg.densenet_structure)
+    names = ["pool0"] + [f"dense{b + 1}" for b in range(nb)] + [f"transition{b + 1}" for b in range(nb - 1)] + ["condense"]
+    errs = {}
+    for which, eng in (("event", rt.ev_engine), ("prong", rt.pr_engine)):
+        pfx = f"network.prong_embedding.{which}_pixel_embedding"
+        for nm in names:
+            key = f"traintap_samp:{pfx}:{nm}"
+            if key not in g:
+                continue
+            if nm == "pool0":                                         # = the first initial_pixel_dim channels of dense block 1's buffer
+                t = eng.tap("dense1")[..., :cfg.initial_pixel_dim]
+            elif nm.startswith("transition"):                         # = the first channels of the next block's buffer
+                b = int(nm[10:])
+                c_in = cfg.initial_pixel_dim
+                for bb in range(b):
+                    c_in = (c_in + cfg.densenet_structure[bb] * cfg.densenet_growth_rate) // 2
+                t = eng.tap(f"dense{b + 1}")[..., :c_in]
+            else:
+                t = eng.tap(nm)
+            t = t.float().cpu()
+            t = t.reshape(t.shape[0], -1) if nm == "condense" else t.permute(0, 3, 1, 2).contiguous()
+            stat, samp = tap_sample(t)
+            r_stat, r_samp = g[key.replace("_samp:", "_stat:")], g[key]
+            e = max(float(np.abs(samp - r_samp).max()) / max(float(np.abs(r_samp).max()), 1e-12),
+                    float(np.abs(stat - r_stat).max()) / max(float(np.abs(r_stat).max()), 1e-12))
+            errs[f"{which}:{nm}"] = e
+    return errs
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_bf16_full_model_logit_error_vs_reference(name):
     """The throughput mode end to end (precision="bf16": bf16 DenseNets, fp32 token path) against the reference's fp32 golden
-    logits, next to the error of the reference's own bf16 autocast run on the same case (dropout = noise = 0)."""
+    logits, next to the error of the reference's own bf16 autocast run on the same case (dropout = noise = 0); train mode gated on
+    the embedder maps in front of the first BatchNorm1d (see the comment above)."""
     cfg, over, batch, g = load_case(name)
     sd = O.fill_state(cfg, int(g["weight_seed"]))
     model = build_trainer(cfg, sd, precision="bf16")
@@ -125,12 +163,17 @@ def test_bf16_full_model_logit_error_vs_reference(name):
     model.train()
     with torch.no_grad():
         _, _, ev, pr = model.shared_step(dbatch)
+    torch.cuda.synchronize()
     t_ev, t_pr = rel_err(ev.cpu(), g["train_event_logits"]), rel_err(pr.cpu(), g["train_prong_logits"])
+    taps = _train_tap_errors(model, cfgt, g)
     _, band = autocast_band(name)
     print(f"BF16 LOGIT ERROR {name}: eval event {e_ev:.3e} prong {e_pr:.3e}; train event {t_ev:.3e} prong {t_pr:.3e}   "
           f"[reference under bf16 autocast: eval {band[0]:.3e} {band[1]:.3e}; train {band[2]:.3e} {band[3]:.3e}]")
+    print(f"BF16 TRAIN TAPS {name} (max-norm rel. vs the reference's fp32 train-mode taps):", {k: f"{v:.2e}" for k, v in taps.items()})
     assert max(e_ev, e_pr) < BF16_EVAL_GATE and max(e_ev, e_pr) <= BAND_SLACK * max(band[0], band[1])
-    assert max(t_ev, t_pr) <= TRAIN_BAND_SLACK * max(band[2], band[3])
+    assert len(taps) >= 2 * (len(cfgt.densenet_structure) + 2)
+    assert max(taps.values()) <= BF16_TRAIN_TAP_GATE, taps
+    assert np.isfinite(t_ev) and np.isfinite(t_pr)
 
 
 def test_cpu_tensors_fail_loudly():

@@ -81,11 +81,11 @@ def test_sdxl_embedder_forward_backward_vs_oracle(mode, tol, gtol):
     assert not bad, bad[:8]
 
 
-def _run_wide(shape=(264, 280)):
-    """Width-64 embedder on two maps of `shape` (bf16): taps of the 64-channel stages and every gradient."""
+def _run_wide(shape=(264, 280), n_maps=1):
+    """Width-64 embedder on `n_maps` maps of `shape` (bf16): taps of the 64-channel stages and every gradient."""
     cfg = _cfg(initial_pixel_dim=64, pixel_embedding_dim=512, pixel_shape=tuple(shape))
     sd = O.fill_state(cfg, 13)
-    batch = O.synthetic_batch([1], 6, cfg)
+    batch = O.synthetic_batch([n_maps], 6, cfg)
     n_img = int(batch[7].sum())
     d_out = torch.randn(n_img, 512, generator=torch.Generator().manual_seed(4))
     eng, data, grads = _engine(cfg, sd, 1, True)
@@ -211,4 +211,59 @@ def test_sdxl_production_width_at_400x280_vs_oracle(which):
         worst.append((((mine - r.double()).norm() / r.double().norm().clamp_min(1e-30)).item(), k))
     worst.sort(reverse=True)
     print("worst gradient rel L2:", worst[:4])
+    assert worst[0][0] < 8e-2, worst[:6]
+
+
+def _per_image_rel(mine, ref):
+    """rel L2 error of every image of an [n, ...] tensor (a mixed-up per-image GroupNorm sum or a packed-tile pixel taken from the
+    neighbouring image shows up in ONE image's figure and would be diluted in the batch norm)."""
+    n = ref.shape[0]
+    d = (mine.double() - ref.double()).reshape(n, -1).norm(dim=1)
+    return (d / ref.double().reshape(n, -1).norm(dim=1).clamp_min(1e-30)).tolist()
+
+
+def test_sdxl_production_width_five_maps_forward_400x280_vs_oracle():
+    """the production-width kernels on SEVERAL maps.  `TileMap` (csrc/sdxl_conv3x3.hip) packs several images side by
+    side / stacked into one 8x32 tile once the maps are <= 15 wide (block 5 onwards at 400x280: 12x8, 6x4, 3x2, 1x1), and the convolution
+    epilogues add a tile's GroupNorm sums per image -- with one map neither the multi-image branch of the tile walk nor per-image sums
+    inside a packed tile run.  Five distinct prong maps (config 4 runs 144), every tap and the output per image against the fp32 oracle."""
+    from transformercvn.hip.engine import SdxlEngine
+    cfg = O.tutorial_config(embedder="sdxl", dropout=0.0, pixel_noise_std=0.0)
+    pfx = PFX
+    pix, _, _ = O.embed_dims(cfg)
+    n = 5
+    sd = {k: v for k, v in O.fill_state(cfg, 19).items() if k.startswith(pfx + ".")}
+    batch = O.synthetic_batch([n], 21, cfg)
+    coords, values = batch[5], batch[6]
+    taps = {}
+    with torch.no_grad():
+        ref = S.sdxl_forward({k: v.float() for k, v in sd.items()}, pfx, O.preprocess_pixels(cfg, coords, values.float(), False), taps)
+    assert ref.shape == (n, pix) and (ref[0] - ref[1]).abs().max() > 1e-3          # distinct maps, distinct embeddings
+    eng = SdxlEngine(cfg.pixel_dim, pix, cfg.initial_pixel_dim, 2, 4, 400, 280, 1)
+    eng.bind({k[len(pfx) + 1:]: v.cuda().contiguous() for k, v in sd.items()}, None)
+    out = torch.empty(n, pix, device="cuda")
+    eng.forward(coords.cuda(), values.cuda(), n, out, train=False, seed=1)
+    torch.cuda.synchronize()
+    errs = {}
+    for tap in ("conv_in", "block0", "block1", "block2", "block3", "block4", "block5", "block6", "block7", "block8", "mid"):
+        mine = eng.tap(tap).permute(0, 3, 1, 2).float().cpu()
+        errs[tap] = max(_per_image_rel(mine, taps[f"{pfx}:{tap}"]))
+    errs["out"] = max(_per_image_rel(out.cpu(), ref))
+    print("sdxl production width, 5 maps at 400x280, bf16 vs fp32 oracle: worst per-image rel L2", errs)
+    assert max(errs.values()) < 3e-2, errs
+
+
+def test_sdxl_production_width_five_maps_gradients_264x280_vs_oracle():
+    """The same multi-map coverage for backward (data gradients through packed tiles, weight gradients summed over the images of a packed
+    tile, GroupNorm backward sums per image): five distinct 264x280 maps (deep maps 33x35 ... 1x1; packed from 8x8 down), every gradient
+    against the fp32 oracle inside the bf16 band of the one-map test, plus forward taps per image."""
+    n = 5
+    cfg, sd, batch, d_out, out, taps, grads = _run_wide((264, 280), n)
+    o_ref, o_taps, g_ref = _oracle(cfg, sd, batch, d_out, dtype=torch.float32)
+    e_out = max(_per_image_rel(out, o_ref))
+    e_taps = {k: max(_per_image_rel(taps[k].permute(0, 3, 1, 2), o_taps[f"{PFX}:{k}"])) for k in taps}
+    worst = sorted(((((grads[k].double().reshape(r.shape) - r.double()).norm() / r.double().norm().clamp_min(1e-30)).item(), k)
+                    for k, r in g_ref.items() if "to_q" not in k and "to_k" not in k), reverse=True)
+    print("sdxl width 64..512, 5 maps at 264x280: out", e_out, "taps", e_taps, "worst gradients", worst[:4])
+    assert e_out < 3e-2 and max(e_taps.values()) < 3e-2, (e_out, e_taps)
     assert worst[0][0] < 8e-2, worst[:6]
