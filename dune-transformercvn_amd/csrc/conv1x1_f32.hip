@@ -423,7 +423,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 }  // namespace
 
 bool conv1x1_fwd_f32_ok(const ConvFwdArgs& a) {
-    if (!conv3x3_tile_enabled() || a.mode != MODE_F32 || a.amode != A_1X1 || a.N != 128 || a.K > MAXC || a.K < 1 || (a.K & 3) || a.drop_p > 0.f) return false;
+    if (!conv3x3_tile_enabled() || a.mode != MODE_F32 || a.amode != A_1X1 || a.N != 128 || a.K > MAXC || a.K < 1 || (a.K & 3) || a.drop_p > 0.f || a.sc == nullptr) return false;
     return aligned16(a.A) && aligned16(a.Wk) && (a.lda & 3) == 0 && (a.Kp & 3) == 0;
 }
 int conv1x1_fwd_f32_nblk(const ConvFwdArgs& a) {
@@ -463,7 +463,7 @@ int conv1x1_dgrad_f32(const ConvDgradArgs& a, hipStream_t st) {
 
 bool conv1x1_wgrad_f32_ok(const ConvWgradArgs& a) {
     const ConvFwdArgs& f = a.fa;
-    if (!conv3x3_tile_enabled() || a.mode != MODE_F32 || f.amode != A_1X1 || a.e.N != 128 || a.nfast || f.K > MAXC || f.K < 1 || (f.K & 3)) return false;
+    if (!conv3x3_tile_enabled() || a.mode != MODE_F32 || f.amode != A_1X1 || a.e.N != 128 || a.nfast || f.K > MAXC || f.K < 1 || (f.K & 3) || f.sc == nullptr) return false;
     return aligned16(f.A) && (f.lda & 3) == 0;
 }
 int conv1x1_wgrad_f32(const ConvWgradArgs& a, hipStream_t st) {

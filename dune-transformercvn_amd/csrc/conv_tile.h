@@ -121,7 +121,7 @@ __device__ __forceinline__ void load_a8(const ConvFwdArgs& g, const T* __restric
     const int n = min(8, g.K - k);
     if (AMODE == A_1X1) {
         if (vec) load8<T>(A + ri.base + k, v); else load8_guard<T>(A + ri.base + k, n, v);
-        act8<T>(g, k, n, v);
+        if (g.sc != nullptr) act8<T>(g, k, n, v);              // sc == nullptr: A is a materialised operand (fp32 transitions: pooled + activated)
     } else if (AMODE == A_1X1_POOL) {
         float t[8];
         const long offs[4] = {0, g.lda, (long)g.Win * g.lda, (long)(g.Win + 1) * g.lda};

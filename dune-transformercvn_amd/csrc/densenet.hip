@@ -158,7 +158,9 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
         }
         L.XA.push_back(xas);
         const bool tfast = bg.has_trans && fastt_ok(bg.Ctot);
-        L.XP.push_back(tfast ? b.take((long)n * (bg.H / 2) * (bg.W / 2) * bg.ldp * esz) : -1);   // row stride bg.ldp, zero padded
+        // fp32 mode (round 4): the same materialised operand feeds the generic forward / weight-gradient kernels of the transition
+        const bool tmat32 = bg.has_trans && cfg.mode == MODE_F32 && conv3x3_tile_enabled() && (bg.ld & 3) == 0;
+        L.XP.push_back((tfast || tmat32) ? b.take((long)n * (bg.H / 2) * (bg.W / 2) * bg.ldp * esz) : -1);   // row stride bg.ldp, zero padded
         L.bstatD.push_back(b.take((long)bg.ld * 16));
         max_part = std::max(max_part, 512L * std::max(mid, bg.Ctot) * 16);   // every conv launcher uses <= 512 workgroups
         maxY = std::max(maxY, M * mid);
@@ -538,10 +540,11 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             const WkEntry& e = wk_find(bg.tw, 0);
             Tab t = tab(bg.tn);
             const long Mn = (long)n * nb.H * nb.W;
-            const bool fastt = L.XP[bi] >= 0;
-            if (fastt) {
+            const bool fastt = L.XP[bi] >= 0 && mode == MODE_BF16;
+            const bool mat32 = L.XP[bi] >= 0 && mode == MODE_F32;
+            if (fastt || mat32) {
                 ActPoolArgs ap{D, bg.ld, n, bg.H, bg.W, bg.Ctot, t.sc, t.sh, data[bg.ta], ws + L.XP[bi], bg.ldp};
-                if ((rc = act_pool_bf16(ap, st))) return rc;
+                if ((rc = fastt ? act_pool_bf16(ap, st) : act_pool_f32(ap, st))) return rc;
             }
             if (fastt) {
                 const WkEntry& ef = wk_find(bg.tw, 0, 1);
@@ -557,6 +560,9 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             a.mode = mode; a.amode = A_1X1_POOL; a.A = D; a.lda = bg.ld; a.M = (int)Mn; a.N = bg.Ctot / 2; a.K = bg.Ctot;
             a.Kp = e.Kp; a.C = bg.Ctot; a.H = nb.H; a.W = nb.W; a.Hin = bg.H; a.Win = bg.W;
             a.sc = t.sc; a.sh = t.sh; a.sl = data[bg.ta];
+            if (mat32) {            // pooled + activated operand materialised above: a plain 1x1 convolution over it (K padded to ldp: zero columns x zero weights)
+                a.amode = A_1X1; a.A = ws + L.XP[bi]; a.lda = bg.ldp; a.K = bg.ldp; a.C = bg.ldp; a.sc = nullptr; a.sh = nullptr; a.sl = nullptr;
+            }
             a.Wk = ws + L.wk + e.off; a.bias = data[bg.tb]; a.Out = ws + L.D[bi + 1]; a.ldo = nb.ld; a.n_off = 0;
             a.part = train ? part : nullptr; a.nblk = conv_fwd_grid((int)Mn);
             if ((rc = conv_fwd(a, st))) return rc;

@@ -149,7 +149,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
     TCVN_CHECK(hipMemsetAsync(ws + L.pqD[0], 0, (size_t)(L.zero_end - L.pqD[0]), st));
     for (size_t bi = 0; bi + 1 < blocks.size(); ++bi) {
         const long bytes = (long)n * blocks[bi].H * blocks[bi].W * blocks[bi].ld * esz;
-        if (L.XP[bi] >= 0) {
+        if (L.XP[bi] >= 0 && mode == MODE_BF16) {
             if ((rc = zero_pool_remainder(ws + L.G[bi], blocks[bi].ld, n, blocks[bi].H, blocks[bi].W, blocks[bi + 1].H, blocks[bi + 1].W, st))) return rc;
         } else TCVN_CHECK(hipMemsetAsync(ws + L.G[bi], 0, (size_t)bytes, st));
     }
@@ -210,7 +210,12 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             w.fa.sc = sc_of(bg.tn); w.fa.sh = sh_of(bg.tn); w.fa.sl = data[bg.ta];
             const int Nt8 = (int)round_up(Nt, 8);
             if ((rc = drain())) return rc;            // the transition uses EY and the slab on `st`
-            if (L.XP[bi] >= 0) {
+            const bool xp_bf16 = L.XP[bi] >= 0 && mode == MODE_BF16;
+            if (L.XP[bi] >= 0 && mode == MODE_F32) {  // fp32: the materialised pooled activation of the forward is the weight gradient's operand
+                w.fa.amode = A_1X1; w.fa.A = ws + L.XP[bi]; w.fa.lda = bg.ldp; w.fa.K = bg.ldp; w.fa.C = bg.ldp;
+                w.fa.sc = nullptr; w.fa.sh = nullptr; w.fa.sl = nullptr;
+            }
+            if (xp_bf16) {
                 // materialise the output gradient once (+ bias gradient), then dW = ET^T x XP on the TN GEMM
                 SlabJob bias_job{};
                 EffMatArgs em{e, Mn, ws + L.ey, Nt8, grad[bg.tb], reinterpret_cast<float*>(ws + L.slab + kSlabGemmBytes), &bias_job};
@@ -219,7 +224,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                               reinterpret_cast<float*>(ws + L.slab), kSlabGemmBytes, Nt, bias_job};
                 if ((rc = gemm_tn_bf16(ga, "k_gemm_tn_bf16<transition>", st))) return rc;
             } else if ((rc = conv_wgrad(w, st))) return rc;
-            if (L.XP[bi] >= 0) {
+            if (xp_bf16) {
                 const WkEntry& etf = wk_find(bg.tw, 1, 1);
                 GemmNtArgs ga{};
                 ga.epi = EPI_DGRAD_POOL; ga.A = ws + L.ey; ga.lda = Nt8; ga.K = Nt8; ga.M = Mn; ga.N = bg.Ctot;

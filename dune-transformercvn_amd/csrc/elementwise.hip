@@ -277,6 +277,43 @@ __global__ __launch_bounds__(256) void k_act_pool_bf16(const ActPoolArgs a) {
     }
 }
 
+// fp32 parity mode (round 4): the same materialised operand for the transitions.  The generic implicit-GEMM kernels regenerated the
+// pooled activation per operand element (four loads + four BatchNorm/PReLU evaluations, tables from global memory) in BOTH the forward
+// and the weight-gradient loader -- k_conv_wgrad<float, A_1X1_POOL> was bound by that loader (9.6 ms per step).  One thread = one pooled
+// pixel x 4 channels; columns [C, ldo) are written as zeros (they are GEMM K-padding).
+__global__ __launch_bounds__(256) void k_act_pool_f32(const ActPoolArgs a) {
+    const float* __restrict__ X = reinterpret_cast<const float*>(a.X);
+    float* __restrict__ O = reinterpret_cast<float*>(a.Out);
+    const int Ho = a.Hin / 2, Wo = a.Win / 2, cpr = (int)(a.ldo >> 2);
+    const long total = (long)a.n_img * Ho * Wo * cpr;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long mo = idx / cpr;
+        const int c = (int)(idx - mo * cpr) * 4;
+        const long row = mo / Wo;
+        const int wo = (int)(mo - row * Wo);
+        const long img = row / Ho;
+        const int ho = (int)(row - img * Ho);
+        const long p00 = ((long)img * a.Hin + 2 * ho) * a.Win + 2 * wo;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c + 4 <= a.C) {
+            const float4 sc = make_float4(a.sc[c], a.sc[c + 1], a.sc[c + 2], a.sc[c + 3]), sh = make_float4(a.sh[c], a.sh[c + 1], a.sh[c + 2], a.sh[c + 3]);
+            const float4 sl = make_float4(a.sl[c], a.sl[c + 1], a.sl[c + 2], a.sl[c + 3]);      // (parameter views: no alignment promise)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(X + (p00 + (k >> 1) * a.Win + (k & 1)) * a.ldx + c);
+                acc[0] += prelu(fmaf(v.x, sc.x, sh.x), sl.x); acc[1] += prelu(fmaf(v.y, sc.y, sh.y), sl.y);
+                acc[2] += prelu(fmaf(v.z, sc.z, sh.z), sl.z); acc[3] += prelu(fmaf(v.w, sc.w, sh.w), sl.w);
+            }
+        } else {
+            for (int j = 0; j < 4 && c + j < a.C; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    acc[j] += prelu(fmaf(X[(p00 + (k >> 1) * a.Win + (k & 1)) * a.ldx + c + j], a.sc[c + j], a.sh[c + j]), a.sl[c + j]);
+        }
+        *reinterpret_cast<float4*>(O + mo * a.ldo + c) = make_float4(acc[0] * 0.25f, acc[1] * 0.25f, acc[2] * 0.25f, acc[3] * 0.25f);
+    }
+}
+
 // ---- weight re-layout -----------------------------------------------------------------------------------------------
 // transpose == 0 : logical B[n][tap*Cin + c] = src[n][c][tap]                   (forward / wgrad operand layout)
 // transpose == 1 : logical B[c][tap*N + n]   = src[n][c][tap]   (dgrad operand: rows = input channel, k = (tap, out ch))
@@ -430,6 +467,16 @@ int act_pool_bf16(const ActPoolArgs& a, hipStream_t st) {
     if (px <= 0) return 0;
     const long g = (px + 256 / cpr - 1) / (256 / cpr);
     hipLaunchKernelGGL(k_act_pool_bf16, dim3((unsigned)(g < 4096 ? g : 4096)), dim3(256), 3 * cpr * 8 * sizeof(float), st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int act_pool_f32(const ActPoolArgs& a, hipStream_t st) {
+    if ((a.ldx & 3) || (a.ldo & 3) || a.ldo < a.C || (reinterpret_cast<uintptr_t>(a.X) & 15) || (reinterpret_cast<uintptr_t>(a.Out) & 15)) return -2;
+    const long total = (long)a.n_img * (a.Hin / 2) * (a.Win / 2) * (a.ldo >> 2);
+    if (total <= 0) return 0;
+    const long g = (total + 255) / 256;
+    hipLaunchKernelGGL(k_act_pool_f32, dim3((unsigned)(g < 8192 ? g : 8192)), dim3(256), 0, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

@@ -198,7 +198,7 @@ int pool0_bwd_grid(int n_img, int Hin, int Win);
 
 // bf16 TN GEMM over pixels (gemm_tn.hip): C[i][j] += sum_m L[m][i] * R[m][j]
 // one reduction job: dst[i] += sum_{s < nslab} slab[s*stride + i], i < count
-struct SlabJob { const float* slab; float* dst; int nslab; long count, stride; int ny, per_y; };
+struct SlabJob { const float* slab; float* dst; int nslab; long count, stride; int ny, per_y; int v4; };   // v4: 16-B loads (count, stride multiples of 4, 16-B aligned)
 SlabJob slab_job(const float* slab, int nslab, long count, float* dst, long stride);
 int slab_reduce2(const SlabJob& a, const SlabJob& b, hipStream_t st);          // two independent jobs in one launch (b may be empty)
 struct GemmTnArgs { const void* L; long ldl; int Li; const void* R; long ldr; int Rj; long M; float* C; long ldc; const void* zeros;
@@ -246,6 +246,7 @@ int eff_materialize_bf16(const EffMatArgs& a, hipStream_t st);
 // XP[m'][c] = bf16( 1/4 sum_{2x2} prelu(D[pixel][c]*sc + sh, sl) )  (pooled activation in front of a transition's 1x1 conv)
 struct ActPoolArgs { const void* X; long ldx; int n_img, Hin, Win, C; const float *sc, *sh, *sl; void* Out; long ldo; };
 int act_pool_bf16(const ActPoolArgs& a, hipStream_t st);
+int act_pool_f32(const ActPoolArgs& a, hipStream_t st);      // fp32 operands; C % 4 == 0; columns [C, ldo) := 0
 
 // bf16 stem kernels (stem.hip)
 int pool0_bwd_vec_grid(int n_img, int Hin, int Win);
