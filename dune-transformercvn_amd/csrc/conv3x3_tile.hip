@@ -424,21 +424,22 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
     // 8-channel chunk (cc) for all rows: its 24 table values are read from LDS once per call.
     auto xform_rows = [&](int row0, int slot0, int n, int w0, int nw) {
         const int rsub = lane >> 4, cc = lane & 15;
-        const Act8 tb = act8_load(xtab, cc);
         for (int rg0 = w0; rg0 * 4 < n; rg0 += 4 * nw) {
             int m4[4];
             u16x8 v[4];
             char* p[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) m4[j] = tbl[(row0 + (rg0 + nw * j) * 4 + rsub) & (PAIR_TBL - 1)];
+            // every LDS read of the trip -- table entries, image chunks, the 24 table values -- is requested before the first use
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int rg = rg0 + nw * j;
-                const int rr = wrap(slot0 + (rg * 4 < n ? rg * 4 : 0)) + rsub;
+                const bool in = rg * 4 < n;
+                m4[j] = tbl[(row0 + (in ? rg * 4 : 0) + rsub) & (PAIR_TBL - 1)];
+                if (!in) m4[j] = -1;
+                const int rr = wrap(slot0 + (in ? rg * 4 : 0)) + rsub;
                 p[j] = smem + rr * 256 + ((cc ^ (rr & 15)) << 4);
-                if (rg * 4 >= n) m4[j] = -1;
                 v[j] = *reinterpret_cast<const u16x8*>(p[j]);
             }
+            const Act8 tb = act8_load(xtab, cc);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (m4[j] >= 0) *reinterpret_cast<u16x8*>(p[j]) = act8_apply(v[j], tb);      // padding rows stay the zeros the DMA wrote
@@ -801,27 +802,29 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         };
         // act_fused: the image rows arrive RAW (the bottleneck map itself); the helper wave that requested a row group applies the
         // layer's BatchNorm + PReLU to it in LDS once its DMAs have landed, in front of the tile barrier (same row groups as dma_rows)
+        // (phase counters, first version: 3 630 cycles per wave and tile for 8 chunks -- three dependent LDS round trips per group of four
+        // chunks and the 24 table values re-read per call; now every LDS read of a call is requested before the first use and the
+        // thread's table values stay in registers for the whole launch)
+        Act8 xtb;
         auto xform_rows = [&](int row0, int n) {
             const int rsub = lane >> 4, cc = lane & 15;
-            const Act8 tb = act8_load(xtab, cc);
-#pragma unroll 2
-            for (int i0 = 0; i0 < 24; i0 += 4) {
-                if ((w4 + 4 * i0) * 4 >= n) break;
-                int mr[4];
-                u16x8 v[4];
-                char* p[4];
+            for (int i0 = 0; (w4 + 4 * i0) * 4 < n; i0 += 8) {
+                int mr[8];
+                u16x8 v[8];
+                char* p[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 8; ++j) {
                     const int rg = w4 + 4 * (i0 + j);
                     const bool in = rg * 4 < n;
                     const int row = row0 + (in ? rg * 4 : 0) + rsub;
-                    mr[j] = in ? tbl[row & (WG_TBL - 1)] : -1;
+                    mr[j] = tbl[row & (WG_TBL - 1)];
+                    if (!in) mr[j] = -1;
                     p[j] = smem + (row & (WG_RING - 1)) * 256 + ((cc ^ (row & 15)) << 4);
                     v[j] = *reinterpret_cast<const u16x8*>(p[j]);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (mr[j] >= 0) *reinterpret_cast<u16x8*>(p[j]) = act8_apply(v[j], tb);
+                for (int j = 0; j < 8; ++j)
+                    if (mr[j] >= 0) *reinterpret_cast<u16x8*>(p[j]) = act8_apply(v[j], xtb);
             }
         };
         // With the eff rows materialised by the data-gradient kernel (e.ey): a tile's 128 rows x 64 B arrive by DMA like the image rows,
@@ -856,6 +859,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         if (ntl > 0) fill_rows(0, nrows4 + min(ntl - 1, 2) * TP);          // tile 0's image rows, the new rows of tiles 1 and 2
         if (xf) act_tab_fill(xtab, fa.sc, fa.sh, fa.sl, htid, 256);
         __syncthreads();                                                    // (1)
+        if (xf) xtb = act8_load(xtab, lane & 15);
         u16x8 gv[2], xv[2];
         uint32_t kw[2];
         int mm[2] = {-1, -1};
@@ -877,9 +881,23 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         int cur = 0;
         PAIR_T0();
         if (EYs != nullptr) {
+            // act_fused: the 128 new image rows of tile il+1 travel HBM -> registers (8 x 16 B per lane) instead of HBM -> LDS, are activated in
+            // registers and written to the ring once.  The DMA + in-place variant needed an LDS read and a second LDS write per chunk, queued
+            // behind the multiplying waves' 160 transposed reads per tile on the one LDS pipe of the CU: 3 200-3 600 cycles per wave and tile
+            // in the phase counters (the multiplying waves then waited 2 500 of 7 400 cycles at the barrier).
+            u16x8 rv[8];
+            int rm[8];
+            const int rsub_x = lane >> 4, cc_x = lane & 15;
             for (int il = 0; il < ntl; ++il, cur ^= 1) {
                 if (il + 1 < ntl) {
-                    dma_rows(il * TP + nrows4, TP);                        // image: the 128 rows tile il+1 does not share with tile il
+                    if (xf) {
+                        const int row0 = il * TP + nrows4;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) rm[j] = tbl[(row0 + (w4 + 4 * j) * 4 + rsub_x) & (WG_TBL - 1)];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            rv[j] = *reinterpret_cast<const u16x8*>(YA + (long)(rm[j] >= 0 ? rm[j] : 0) * 128 + cc_x * 8);
+                    } else dma_rows(il * TP + nrows4, TP);                 // image: the 128 rows tile il+1 does not share with tile il
                     dma_eff((il + 1) * TP + q.halo, cur ^ 1);              // its eff rows
                 }
                 PAIR_PH(8);
@@ -887,9 +905,17 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                 PAIR_PH(9);
                 if (il + 3 < ntl) fill_rows((il + 2) * TP + nrows4, TP);   // new rows of tile il+3
                 PAIR_PH(10);
-                if (xf) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's image rows of tile il+1 are in: activate them in place
-                    if (il + 1 < ntl) xform_rows(il * TP + nrows4, TP);
+                if (xf && il + 1 < ntl) {
+                    const int row0 = il * TP + nrows4;
+                    PAIR_PH(11);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int row = row0 + (w4 + 4 * j) * 4 + rsub_x;
+                        u16x8 o = act8_apply(rv[j], xtb);
+                        if (rm[j] < 0) o = u16x8{0, 0, 0, 0, 0, 0, 0, 0};                  // padding position: a zero row
+                        *reinterpret_cast<u16x8*>(smem + (row & (WG_RING - 1)) * 256 + ((cc_x ^ (row & 15)) << 4)) = o;
+                    }
+                    PAIR_PH(13);
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (tile)
                 PAIR_PH(12);

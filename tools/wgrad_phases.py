@@ -35,7 +35,7 @@ v = list(buf)
 tiles = (n * 101 * 71 + 127) // 128
 waves = 4 * tiles / 16       # wave-tiles that report (every 16th workgroup)
 names = {0: "M k loop (tr reads + 72 MFMA)", 1: "M barrier", 8: "H dma issue (17 DMA)", 9: "H eff loads + store (hash)",
-         10: "H table fill", 11: "H wait vmcnt(0)", 12: "H barrier"}
+         10: "H table fill", 11: "H wait vmcnt(0) (act_fused)", 13: "H in-LDS activation (act_fused)", 12: "H barrier"}
 for k in sorted(names):
     print(f"{names[k]:36s} {v[k] / 1e6:10.1f} Mcycles   {v[k] / waves:8.0f} cycles per wave and tile")
 print("tiles", tiles, "sum M", sum(v[:8]) / waves, "sum H", sum(v[8:]) / waves)
