@@ -17,18 +17,18 @@ __global__ __launch_bounds__(256) void k_bn_link(const BnLinkArgs a) {
     if (a.train) {
         if (c >= a.c_new0 && c < a.c_new0 + a.n_new) {
             double s1 = 0, s2 = 0;
-            int b = lane;
-            for (; b + 192 < a.nblk; b += 256) {                // four partial rows per trip (eight loads in flight per lane)
-                const double* p0 = a.part + ((long)b * a.part_ld + (c - a.c_new0)) * 2;
-                const double* p1 = p0 + (long)64 * a.part_ld * 2;
-                const double* p2 = p0 + (long)128 * a.part_ld * 2;
-                const double* p3 = p0 + (long)192 * a.part_ld * 2;
-                const double a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1], c0 = p2[0], c1 = p2[1], d0 = p3[0], d1 = p3[1];
-                s1 += (a0 + b0) + (c0 + d0); s2 += (a1 + b1) + (c1 + d1);
-            }
-            for (; b < a.nblk; b += 64) {
-                const double* p = a.part + ((long)b * a.part_ld + (c - a.c_new0)) * 2;
-                s1 += p[0]; s2 += p[1];
+            // eight partial rows per trip: every row of a launch with <= 512 workgroups in one round trip (see k_bn_bwd_link)
+            for (int b = lane; b < a.nblk; b += 512) {
+                double v[8][2];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int bb = b + 64 * i;
+                    const double* p = a.part + ((long)(bb < a.nblk ? bb : b) * a.part_ld + (c - a.c_new0)) * 2;
+                    v[i][0] = p[0]; v[i][1] = p[1];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (b + 64 * i < a.nblk) { s1 += v[i][0]; s2 += v[i][1]; }
             }
             s1 = wave_sum(s1); s2 = wave_sum(s2);
             mean = s1 / (double)a.count;

@@ -15,18 +15,20 @@ __global__ __launch_bounds__(256) void k_bn_bwd_link(const BnBwdLinkArgs a) {
     if (c >= a.C) return;
     double s1 = 0, t2 = 0, s3 = 0;
     int b = lane;
-    for (; b + 192 < a.nblk; b += 256) {                        // four partial rows per trip: twelve loads in flight per lane (the fp32
-        const double* p0 = a.part + ((long)b * a.C + c) * 3;    // tile kernels leave thousands of rows; one row per trip is a chain
-        const double* p1 = p0 + (long)64 * a.C * 3;             // of L2 round trips)
-        const double* p2 = p0 + (long)128 * a.C * 3;
-        const double* p3 = p0 + (long)192 * a.C * 3;
-        const double a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
-        const double c0 = p2[0], c1 = p2[1], c2 = p2[2], d0 = p3[0], d1 = p3[1], d2 = p3[2];
-        s1 += (a0 + b0) + (c0 + d0); t2 += (a1 + b1) + (c1 + d1); s3 += (a2 + b2) + (c2 + d2);
-    }
-    for (; b < a.nblk; b += 64) {
-        const double* p = a.part + ((long)b * a.C + c) * 3;
-        s1 += p[0]; t2 += p[1]; s3 += p[2];
+    // Eight partial rows per trip = every row of a launch with <= 512 workgroups (all of them) in ONE round trip: 24 loads in flight
+    // per lane.  This kernel sits between two convolutions of the critical chain while the other embedder's kernels keep the memory system
+    // busy: each dependent trip cost a full loaded-latency round trip (fp32 mode: 25 us per launch with two trips, 132 launches per step).
+    for (; b < a.nblk; b += 512) {
+        double v[8][3];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int bb = b + 64 * i;
+            const double* p = a.part + ((long)(bb < a.nblk ? bb : b) * a.C + c) * 3;
+            v[i][0] = p[0]; v[i][1] = p[1]; v[i][2] = p[2];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (b + 64 * i < a.nblk) { s1 += v[i][0]; t2 += v[i][1]; s3 += v[i][2]; }
     }
     s1 = wave_sum(s1); t2 = wave_sum(t2); s3 = wave_sum(s3);
     if (lane != 0) return;
