@@ -51,6 +51,7 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     L.ey = b.take(maxY * esz);
     L.ey2 = b.take(maxY * esz);                    // second EY buffer: the weight-gradient stream may still read the previous one
     L.slab = b.take(kSlabBytes);
+    L.slab1 = cfg.mode == MODE_BF16 ? b.take(kSlabBytes) : -1;
     L.pqY = b.take((long)mid * 8);
     L.du0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
     L.pq0 = b.take((long)cfg.init_ch * 8);
@@ -89,6 +90,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
     // side stream beside it.  Shared state: the slab (side stream only between drains), EY (double buffered, released by
     // ev_done), the bias column-sum partials (two halves of the slab tail).  TCVN_BWD_SERIAL=1 keeps everything on `st`.
     static const bool serial_env = TCVN_KNOB_SET("TCVN_BWD_SERIAL");
+    static const bool no_fuse1 = TCVN_KNOB_SET("TCVN_NO_BWD1_FUSE");      // validation build: the three-kernel 1x1 backward (eff copy, TN GEMM, NT GEMM)
     const bool side_on = fast3x3 && !serial_env && backward_overlap_enabled();
     if (side_on && (rc = ensure_side())) return rc;
     int seq = 0;                                   // parity of the EY buffer / tail half; reset by drain()
@@ -292,6 +294,25 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 if ((rc = conv_wgrad(w, par ? side_st : st))) return rc;
             }
             EffSrc e1{DU, mid, Y, mid, 0, mid, PY, QY, 0.f, 0, 0};
+            if (L.XA[bi][l] >= 0 && !no_fuse1 && mid == 128 && L.slab1 >= 0) {
+                // Fused 1x1 backward (round 4, bwd1x1_fused.hip): effective gradient formed in LDS, bias / data / weight gradient and the norm1
+                // backward epilogue in one pass -- no EY in HBM, no read of the activated copy XA, one launch (+ its slab reduction) instead
+                // of three (+ one).  It writes G, so it runs on `st`; its slabs are its own (the 3x3 weight gradient on the side stream owns L.slab).
+                const WkEntry& etf = wk_find(ls.w1, 1, 1);
+                const WkEntry& ef = wk_find(ls.w1, 0);
+                Bwd1x1Args fa{};
+                fa.DU = DU; fa.Y = Y; fa.PY = PY; fa.QY = QY; fa.M = M; fa.Xin = D; fa.ldx = bg.ld; fa.cin = ls.cin;
+                fa.sc = sc_of(ls.n1); fa.sh = sh_of(ls.n1); fa.sl = data[ls.a1]; fa.Gout = G; fa.ldg = bg.ld;
+                fa.Wfrag = ws + L.wk + etf.off; fa.Kp = etf.Kp; fa.zeros = ws + L.zeros; fa.part = part;
+                fa.slab = reinterpret_cast<float*>(ws + L.slab1); fa.slab_bytes = kSlabGemmBytes; fa.ldc = ef.Kp;
+                fa.tail = reinterpret_cast<float*>(ws + L.slab1 + kSlabGemmBytes);
+                fa.nblk = bwd1x1_fused_nblk(fa);
+                if (bwd1x1_fused_ok(fa)) {
+                    if ((rc = bwd1x1_fused(fa, gw_of(ls.w1), grad[ls.b1], st))) return rc;
+                    if ((rc = bwd_link(ls.n1, fa.nblk, bstatD, M, P, Q, 1, ls.a1))) return rc;
+                    continue;
+                }
+            }
             {   // conv1 (1x1) weight gradient
                 const WkEntry& ef = wk_find(ls.w1, 0);
                 ConvWgradArgs w{};

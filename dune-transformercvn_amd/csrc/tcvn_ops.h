@@ -237,6 +237,27 @@ bool gemm_nt_ok(const GemmNtArgs& a);
 int gemm_nt_nblk(const GemmNtArgs& a);
 int gemm_nt_bf16(const GemmNtArgs& a, const char* label, hipStream_t st);
 
+// Fused backward of a bottleneck 1x1 convolution (bwd1x1_fused.hip): effective gradient of the 128-channel bottleneck output formed in
+// LDS from (DU, Y, PY, QY), bias gradient, data gradient with the norm1 / PReLU1 backward epilogue (G += sc*dU, statistics partials) and
+// the weight gradient against the activated input, in one pass over the pixels -- replaces eff_materialize_bf16 + gemm_tn_bf16 +
+// gemm_nt_bf16<EPI_DGRAD> of a dense layer.
+struct Bwd1x1Args {
+    const void* DU; const void* Y;          // [M][128] bf16 each: the EffSrc (G, X) of the bottleneck output
+    const float *PY, *QY;                   // [128]
+    long M;
+    const void* Xin; long ldx; int cin;     // raw concat buffer (norm1 input), its row pitch, channels of this layer (cin % 8 == 0)
+    const float *sc, *sh, *sl;              // norm1 (scale, shift) table, PReLU1 slope
+    void* Gout; long ldg;                   // gradient accumulator of the concat buffer (read-add-write on [0, cin))
+    const void* Wfrag; int Kp;              // W1 transposed ([cin][128]) in MFMA fragment order; Kp == 128
+    const void* zeros;
+    double* part; int nblk;                 // [nblk][cin][3]; nblk = bwd1x1_fused_nblk()
+    float* slab; long slab_bytes; long ldc; // per-workgroup weight-gradient tiles [nblk][128][ldc]; ldc = row pitch of the kernel-layout dW1
+    float* tail;                            // [nblk][128] bias column-sum partials
+};
+bool bwd1x1_fused_ok(const Bwd1x1Args& a);
+int bwd1x1_fused_nblk(const Bwd1x1Args& a);
+int bwd1x1_fused(const Bwd1x1Args& a, float* dWk, float* dbias, hipStream_t st);   // + the slab reductions into dWk [128][ldc], dbias [128]
+
 // Materialise an effective gradient: Out[m][n] = bf16(drop * (G[m][c_off+n] + P[n]*X[m][c_off+n] + Q[n])), n < e.N;
 // optionally colsum[n] += sum_m Out[m][n] (bias gradient of the producing convolution).
 struct EffMatArgs { EffSrc e; long M; void* Out; long ldo; float* colsum; float* slab;   // slab: >= 2048*N floats when colsum

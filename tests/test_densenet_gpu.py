@@ -496,3 +496,45 @@ result = dict(out=out, taps=taps, grads=grads, ya_absmax=ya.abs().max().item())
     print("act-fused vs materialised: bit-identical gradients", len(same), "of", len(grads), "; largest differences", errs[:6])
     print("3x3 weight gradients:", [(k, f"{e:.2e}") for e, k in errs if k.endswith("conv2.weight")])
     assert errs[0][0] < GRAD_TOL and len(same) >= 0.75 * len(grads), errs[:8]
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_fused_1x1_backward_matches_three_kernel_path(dropout):
+    """Round 4: k_bwd1x1_fused_bf16 (effective gradient formed in LDS, bias / data / weight gradient and the norm1 backward epilogue in one
+    pass over the pixels) against the three-kernel path it replaces (k_eff_mat -> k_gemm_tn_bf16 + k_gemm_nt_bf16<dgrad>; TCVN_NO_BWD1_FUSE
+    on the validation build, separate process).  Same bf16 operands with the same roundings: the data-gradient chain (everything that
+    flows through G: norm / PReLU parameter gradients of the layers below, conv0) sees bit-identical inputs; the 1x1 weight gradients sum
+    the same products in another order (per-workgroup register tiles over strided 64-pixel tiles instead of contiguous pixel slices).
+    Structure [3, 3] reaches cin = 144 > 128: two column slices per pixel tile (blockIdx.y), the second one partial."""
+    over = dict(densenet_structure=[3, 3], num_encoder_layers=2, dropout=dropout, pixel_noise_std=0.0)
+    cfg = O.tutorial_config(**over)
+    batch = O.synthetic_batch([2, 1], 23, cfg)
+    sd = O.fill_state(cfg, 9)
+    n_img = int(batch[7].sum())
+    d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(6))
+    out, taps, grads = _run_bf16(cfg, sd, batch, True, d_out)
+    from variant_utils import run_on_debug_build
+    ref = run_on_debug_build(f"""
+import test_densenet_gpu as T
+from oracle import tcvn_oracle as O
+cfg = O.tutorial_config(**{over!r})
+batch = O.synthetic_batch([2, 1], 23, cfg)
+sd = O.fill_state(cfg, 9)
+n_img = int(batch[7].sum())
+d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(6))
+out, taps, grads = T._run_bf16(cfg, sd, batch, True, d_out)
+result = dict(out=out, grads=grads)
+""", dict(TCVN_NO_BWD1_FUSE="1"))
+    assert torch.equal(out, ref["out"])
+    errs = sorted(((((grads[k] - ref["grads"][k]).norm() / ref["grads"][k].norm().clamp_min(1e-30)).item(), k)
+                   for k in grads if ref["grads"][k].abs().max() > 0), reverse=True)
+    same = [k for k in grads if torch.equal(grads[k], ref["grads"][k])]
+    print("fused 1x1 backward vs three kernels: bit-identical gradients", len(same), "of", len(grads), "; largest differences", errs[:8])
+    w1 = [(k, f"{e:.2e}") for e, k in errs if k.endswith("conv1.weight")]
+    print("1x1 weight gradients:", w1)
+    is_bias = lambda k: k.endswith(("conv0.bias", "conv1.bias", "conv2.bias", "conv.bias"))      # exact-zero gradients: rounding noise only
+    worst = max(e for e, k in errs if not is_bias(k))
+    assert worst < 2e-5, errs[:8]
+    for k in grads:
+        if is_bias(k):
+            assert (grads[k] - ref["grads"][k]).abs().max().item() < 5e-3, k
