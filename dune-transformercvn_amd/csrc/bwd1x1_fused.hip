@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void k_bwd1x1_fused_bf16(const Bwd1x1Args g
     // the twelve DMAs and the four G loads -- per-lane 64-bit source pointers with their range selects are ~50 registers of loop
     // invariants next to the accumulators.  x chunks beyond cin are never requested: their LDS slots are zeroed once, nothing writes them.
     const int col_chunk = tid & 15;                                        // element-wise roles: 16 threads per row, 8 channels each
-    const bool col_ok = n0 + col_chunk * 8 < N;                            // cin % 8 == 0 (launcher): a chunk is whole or absent
+    const bool col_ok = n0 + col_chunk * 8 < N;                            // a last, partial chunk (cin % 8 != 0) needs no masks: its tables and weight rows
+                                                                           // are zero beyond cin, so G is rewritten unchanged and the activated input is 0 there
     const int d_r0 = (tid >> 6) * 4 + ((tid & 63) >> 4);                   // DMA: this lane's row in row group i is d_r0 + 16*i
     const int d_chunk = (tid & 15) ^ (d_r0 & 15);
     const bool xchunk_ok = n0 + (d_chunk << 3) < N;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd1x1_fused_bf16(const Bwd1x1Args g
 
 bool bwd1x1_fused_ok(const Bwd1x1Args& a) {
     if (!a.DU || !a.Y || !a.Xin || !a.Gout || !a.Wfrag || !a.zeros || !a.part || !a.slab || !a.tail) return false;
-    if (a.cin <= 0 || (a.cin & 7) || a.Kp != 128 || (a.ldx & 7) || (a.ldg & 7) || a.ldc < a.cin || a.ldc > cdiv(a.cin, 128) * 128) return false;
+    if (a.cin <= 0 || a.Kp != 128 || (a.ldx & 7) || (a.ldg & 7) || a.ldc < a.cin || a.ldc > cdiv(a.cin, 128) * 128) return false;
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.DU) | reinterpret_cast<uintptr_t>(a.Y) | reinterpret_cast<uintptr_t>(a.Xin) |
                          reinterpret_cast<uintptr_t>(a.Gout) | reinterpret_cast<uintptr_t>(a.Wfrag) | reinterpret_cast<uintptr_t>(a.slab);
     if (al & 15) return false;

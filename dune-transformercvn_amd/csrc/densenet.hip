@@ -463,6 +463,26 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 fuse_ya = conv3x3_tile_ok(c3);
             }
             if (fuse_ya) last_fused_ya = true;
+            if (xa_skipped.size() != blocks.size()) xa_skipped.assign(blocks.size(), std::vector<char>());
+            if ((int)xa_skipped[bi].size() != bg.L) xa_skipped[bi].assign(bg.L, 0);
+            xa_skipped[bi][l] = 0;
+            // Train mode (round 4): the 1x1 runs on the RAW concat buffer, norm1 + PReLU1 applied to the landed LDS tiles (fwd1x1_fused.hip);
+            // the fused 1x1 backward kernel rebuilds that activation from x, so the activated copy XA is neither written nor read.
+            static const bool no_fuse1 = TCVN_KNOB_SET("TCVN_NO_FWD1_FUSE") || TCVN_KNOB_SET("TCVN_NO_BWD1_FUSE");
+            if (train && fast1 && !no_fuse1 && mid == 128 && mode == MODE_BF16) {
+                const WkEntry& e = wk_find(ls.w1, 0, 1);
+                Tab t1 = tab(ls.n1);
+                Fwd1x1Args fa{};
+                fa.Xin = D; fa.ldx = bg.ld; fa.cin = ls.cin; fa.sc = t1.sc; fa.sh = t1.sh; fa.sl = data[ls.a1]; fa.M = M;
+                fa.Wfrag = ws + L.wk + e.off; fa.Kp = e.Kp; fa.bias = data[ls.b1]; fa.Out = ws + L.Y[bi][l]; fa.zeros = ws + L.zeros;
+                fa.part = part; fa.nblk = fwd1x1_fused_nblk(fa);
+                if (fwd1x1_fused_ok(fa)) {
+                    if ((rc = fwd1x1_fused(fa, st))) return rc;
+                    if ((rc = link(ls.n2, part, fa.nblk, mid, 0, mid, reinterpret_cast<double*>(ws + L.bstatY[bi][l]), M))) return rc;
+                    xa_skipped[bi][l] = 1;
+                    goto conv3;
+                }
+            }
             if (fast1 && xa_materialize()) {     // activated copy of the 1x1 input: operand of the bf16 GEMMs (forward, weight gradient)
                 Tab t1 = tab(ls.n1);
                 ActArgs act{D, bg.ld, M, ls.cin, t1.sc, t1.sh, data[ls.a1], ws + L.XA[bi][l], cin8};
@@ -495,6 +515,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 if ((rc = conv_fwd(a, st))) return rc;
                 if ((rc = link(ls.n2, part, a.nblk, mid, 0, mid, reinterpret_cast<double*>(ws + L.bstatY[bi][l]), M))) return rc;
             }
+        conv3:
             {   // 3x3: Y -> D[:, cin:cin+g]
                 const WkEntry& e = wk_find(ls.w2, 0);
                 Tab t = tab(ls.n2);
@@ -627,6 +648,7 @@ int DenseNetPlan::tap(int n, const char* name, long* off, int* tn, int* th, int*
         if (b < 0 || b >= (int)blocks.size() || l < 0 || l >= blocks[b].L) return -1;
         const bool xa = s[0] == 'x';
         if ((xa && (!xa_materialize() || L.XA[b].empty() || L.XA[b][l] < 0)) || (!xa && L.YA[b].empty())) return -1;
+        if (xa && n == last_n && b < (int)xa_skipped.size() && l < (int)xa_skipped[b].size() && xa_skipped[b][l]) return -1;                 // 1x1 ran on the raw buffer
         if (!xa && n == last_n && b < (int)act_fused.size() && l < (int)act_fused[b].size() && act_fused[b][l]) return -1;   // activated in LDS only
         *off = xa ? L.XA[b][l] : L.YA[b][l]; *th = blocks[b].H; *tw = blocks[b].W;
         *tc = xa ? blocks[b].layers[l].cin : cfg.bn_size * cfg.growth; *tld = xa ? (int)round_up(*tc, 8) : *tc;

@@ -313,6 +313,10 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                     continue;
                 }
             }
+            if (bi < (int)xa_skipped.size() && l < (int)xa_skipped[bi].size() && xa_skipped[bi][l]) {
+                fprintf(stderr, "tcvn: the forward skipped the activated 1x1 input of block %d layer %d but the fused 1x1 backward cannot run\n", bi, l);
+                return -15;
+            }
             {   // conv1 (1x1) weight gradient
                 const WkEntry& ef = wk_find(ls.w1, 0);
                 ConvWgradArgs w{};

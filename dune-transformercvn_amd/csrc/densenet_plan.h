@@ -62,6 +62,8 @@ struct DenseNetPlan {
     std::vector<std::vector<char>> keep_valid;   // [block][layer]: the last train-mode forward stored the layer's dropout keep words
     std::vector<std::vector<char>> act_fused;    // [block][layer]: the last forward ran the 3x3 pair kernel on the RAW bottleneck map (activation applied
                                                  // in LDS, ConvFwdArgs::act_fused): no activated copy YA of that layer exists, the weight gradient does the same
+    std::vector<std::vector<char>> xa_skipped;   // [block][layer]: the last forward ran the fused 1x1 kernel on the raw concat buffer: no activated copy XA of that
+                                                 // layer's input exists, backward must take the fused 1x1 kernel (which rebuilds it from x)
     bool last_fused_ya = false;          // the last forward was an eval pass whose 1x1 GEMMs wrote the activated bottleneck maps only (no raw Y)
     bool last_sparse_stem = false;       // the last forward ran the sparse-aware stem: no dense map / conv0 output exists (backward must match)
     bool sparse_stem_possible() const;   // plan-level condition (bf16, 3 -> 64 channels); the hit count decides per call

@@ -258,6 +258,21 @@ bool bwd1x1_fused_ok(const Bwd1x1Args& a);
 int bwd1x1_fused_nblk(const Bwd1x1Args& a);
 int bwd1x1_fused(const Bwd1x1Args& a, float* dWk, float* dbias, hipStream_t st);   // + the slab reductions into dWk [128][ldc], dbias [128]
 
+// Forward of a bottleneck 1x1 convolution on the RAW concat buffer (fwd1x1_fused.hip): norm1 + PReLU1 applied to the landed LDS tiles,
+// Y[m][0:128] = bf16(act(x) x W1^T + bias), statistics partials of Y -- replaces act_bf16 + gemm_nt_bf16<EPI_FWD> of a dense layer.
+struct Fwd1x1Args {
+    const void* Xin; long ldx; int cin;     // raw concat buffer, row pitch, input channels (<= 512)
+    const float *sc, *sh, *sl;              // norm1 (scale, shift) table, PReLU1 slope
+    long M;
+    const void* Wfrag; int Kp;              // W1 [128][Kp] in MFMA fragment order
+    const float* bias; void* Out;           // Y [M][128] bf16
+    const void* zeros;
+    double* part; int nblk;                 // [nblk][128][2] or null; nblk = fwd1x1_fused_nblk()
+};
+bool fwd1x1_fused_ok(const Fwd1x1Args& a);
+int fwd1x1_fused_nblk(const Fwd1x1Args& a);
+int fwd1x1_fused(const Fwd1x1Args& a, hipStream_t st);
+
 // Materialise an effective gradient: Out[m][n] = bf16(drop * (G[m][c_off+n] + P[n]*X[m][c_off+n] + Q[n])), n < e.N;
 // optionally colsum[n] += sum_m Out[m][n] (bias gradient of the producing convolution).
 struct EffMatArgs { EffSrc e; long M; void* Out; long ldo; float* colsum; float* slab;   // slab: >= 2048*N floats when colsum
