@@ -91,7 +91,11 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
     // ev_done), the bias column-sum partials (two halves of the slab tail).  TCVN_BWD_SERIAL=1 keeps everything on `st`.
     static const bool serial_env = TCVN_KNOB_SET("TCVN_BWD_SERIAL");
     static const bool no_fuse1 = TCVN_KNOB_SET("TCVN_NO_BWD1_FUSE");      // validation build: the three-kernel 1x1 backward (eff copy, TN GEMM, NT GEMM)
-    const bool side_on = fast3x3 && !serial_env && backward_overlap_enabled();
+    // Every width takes the fused kernel.  A/B on MI355X (B = 32 x 8 prongs, validation build): fused for cin <= 256 only 19.76 ms/step, <= 384
+    // 19.39, all layers 19.16 -- although a launch with three or four 128-column slices (block 3: every slice re-reads DU / Y and rebuilds EY)
+    // takes longer than k_eff_mat + k_gemm_nt did (105 against ~58 us at four slices), the step is shorter without the two extra launches
+    // per layer on the main stream and the TN GEMM competing on the side stream.  TCVN_BWD1_MAXCIN (validation build) restores a limit.
+    static const int fuse1_maxcin = TCVN_KNOB_INT("TCVN_BWD1_MAXCIN") > 0 ? TCVN_KNOB_INT("TCVN_BWD1_MAXCIN") : (1 << 30);
     if (side_on && (rc = ensure_side())) return rc;
     int seq = 0;                                   // parity of the EY buffer / tail half; reset by drain()
     bool side_busy = false;
@@ -294,7 +298,8 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 if ((rc = conv_wgrad(w, par ? side_st : st))) return rc;
             }
             EffSrc e1{DU, mid, Y, mid, 0, mid, PY, QY, 0.f, 0, 0};
-            if (L.XA[bi][l] >= 0 && !no_fuse1 && mid == 128 && L.slab1 >= 0) {
+            const bool xa_absent = bi < (int)xa_skipped.size() && l < (int)xa_skipped[bi].size() && xa_skipped[bi][l];
+            if (L.XA[bi][l] >= 0 && !no_fuse1 && mid == 128 && L.slab1 >= 0 && (ls.cin <= fuse1_maxcin || xa_absent)) {
                 // Fused 1x1 backward (round 4, bwd1x1_fused.hip): effective gradient formed in LDS, bias / data / weight gradient and the norm1
                 // backward epilogue in one pass -- no EY in HBM, no read of the activated copy XA, one launch (+ its slab reduction) instead
                 // of three (+ one).  It writes G, so it runs on `st`; its slabs are its own (the 3x3 weight gradient on the side stream owns L.slab).

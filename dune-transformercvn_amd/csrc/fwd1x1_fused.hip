@@ -16,21 +16,21 @@ namespace {
 
 constexpr int ROWS = 64;
 constexpr int TILE = ROWS * 256;                 // one [64][128] bf16 chunk
-constexpr int CLD = 132;                         // C tile leading dimension (floats), padded
+constexpr int CLD = 136;                         // C tile leading dimension (bf16 elements), padded: 272-B rows keep the 16-B epilogue reads conflict-free
 
 template <int NKC> struct FwdCfg {
-    static constexpr int OFF_C = NKC * TILE;                       // fp32 C tile [64][CLD]
-    static constexpr int OFF_TAB = OFF_C + ROWS * CLD * 4;         // [3][NKC*128] floats: scale, shift, slope of the input channels
-    static constexpr int SMEM = OFF_TAB + 3 * NKC * 128 * 4;       // NKC = 2: 69 632 B (two workgroups per CU); NKC = 4: 105 472 B
+    static constexpr int OFF_C = NKC * TILE;                       // bf16 C tile [64][CLD]: + bias and the one rounding happen in MFMA layout
+    static constexpr int OFF_TAB = OFF_C + ROWS * CLD * 2;         // [3][NKC*128] floats: scale, shift, slope of the input channels
+    static constexpr int SMEM = OFF_TAB + 3 * NKC * 128 * 4;       // NKC = 1: 35 328 B, NKC = 2: 53 248 B (three workgroups per CU)
 };
 
 template <int NKC>
-__global__ __launch_bounds__(256, NKC <= 2 ? 2 : 1) void k_fwd1x1_fused_bf16(const Fwd1x1Args g) {
+__global__ __launch_bounds__(256, 3) void k_fwd1x1_fused_bf16(const Fwd1x1Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef FwdCfg<NKC> C;
     constexpr int KS = NKC * 8;
-    float* Cs = reinterpret_cast<float*>(smem + C::OFF_C);
-    double* red = reinterpret_cast<double*>(smem + C::OFF_C);              // [4][128][2], after the last tile
+    bf16* Cs = reinterpret_cast<bf16*>(smem + C::OFF_C);
+    double* red = reinterpret_cast<double*>(smem);                         // [4][128][2], after the last tile (over the x chunks)
     float* tab = reinterpret_cast<float*>(smem + C::OFF_TAB);
 
     const int tid = threadIdx.x;
@@ -56,9 +56,7 @@ __global__ __launch_bounds__(256, NKC <= 2 ? 2 : 1) void k_fwd1x1_fused_bf16(con
         const bool ok = i < K;
         tab[i] = ok ? g.sc[i] : 0.f; tab[NKC * 128 + i] = ok ? g.sh[i] : 0.f; tab[2 * NKC * 128 + i] = ok ? g.sl[i] : 0.f;
     }
-    float cb[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) cb[j] = g.bias[(tid & 15) * 8 + j];
+    const float cbias = g.bias[(tid >> 6) * 32 + (tid & 31)];              // this lane's output column in MFMA layout: wave*32 + (lane & 31)
     float st1[8], st2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
@@ -168,27 +166,23 @@ __global__ __launch_bounds__(256, NKC <= 2 ? 2 : 1) void k_fwd1x1_fused_bf16(con
         __syncthreads();                                                   // the x chunks are free: the next tile travels under the epilogue
         if (mt + gridDim.x < mtiles) request(mt + gridDim.x);
         {
-            float* cw = Cs + 4 * h * CLD + wave * 32 + r;
+            bf16* cw = Cs + 4 * h * CLD + wave * 32 + r;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) cw[(i * 32 + (e & 3) + 8 * (e >> 2)) * CLD] = acc[i][e];
+                for (int e = 0; e < 16; ++e) cw[(i * 32 + (e & 3) + 8 * (e >> 2)) * CLD] = f2bf(acc[i][e] + cbias);
         }
         __syncthreads();
-        // ---- epilogue: + bias, one rounding to bf16, statistics of the rounded values, 16-B stores (a tile of Y is 16 KB contiguous)
+        // ---- epilogue: statistics of the rounded values, 16-B stores (a tile of Y is 16 KB contiguous)
         {
-            const float* crow = Cs + c_r0 * CLD + c8 * 8;
+            const bf16* crow = Cs + c_r0 * CLD + c8 * 8;
             bf16* yb = reinterpret_cast<bf16*>(g.Out) + (m0 + c_r0) * 128 + c8 * 8;
 #pragma unroll
             for (int i = 0; i < ROWS / 16; ++i) {
                 if (m0 + c_r0 + 16 * i < g.M) {
-                    const float4 ca = *reinterpret_cast<const float4*>(crow + i * 16 * CLD);
-                    const float4 cc = *reinterpret_cast<const float4*>(crow + i * 16 * CLD + 4);
-                    const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cc.x, cc.y, cc.z, cc.w};
-                    u16x8 o;
+                    const u16x8 o = *reinterpret_cast<const u16x8*>(crow + i * 16 * CLD);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        o[j] = f2bf(cv[j] + cb[j]);
                         const float x = bf2f(o[j]);
                         st1[j] += x; st2[j] += x * x;
                     }
@@ -226,13 +220,13 @@ __global__ __launch_bounds__(256, NKC <= 2 ? 2 : 1) void k_fwd1x1_fused_bf16(con
 
 bool fwd1x1_fused_ok(const Fwd1x1Args& a) {
     if (!a.Xin || !a.Out || !a.Wfrag || !a.zeros || !a.bias || !a.sc || !a.sh || !a.sl) return false;
-    if (a.cin <= 0 || a.cin > 512 || a.Kp < a.cin || a.Kp > 512 || (a.Kp & 15) || (a.ldx & 7) || a.ldx < a.cin) return false;
+    if (a.cin <= 0 || a.cin > 256 || a.Kp < a.cin || a.Kp > 256 || (a.Kp & 15) || (a.ldx & 7) || a.ldx < a.cin) return false;
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.Xin) | reinterpret_cast<uintptr_t>(a.Out) | reinterpret_cast<uintptr_t>(a.Wfrag);
     return (al & 15) == 0;
 }
 
 int fwd1x1_fused_nblk(const Fwd1x1Args& a) {
-    const int cap = a.Kp <= 256 ? 512 : 256;         // resident workgroups
+    const int cap = 768;                             // resident workgroups: three per CU
     const long mt = (a.M + ROWS - 1) / ROWS;
     return (int)(mt < cap ? mt : cap);
 }
@@ -243,15 +237,15 @@ int fwd1x1_fused(const Fwd1x1Args& a, hipStream_t st) {
     if (a.part != nullptr && a.nblk != fwd1x1_fused_nblk(a)) { fprintf(stderr, "tcvn: fwd1x1_fused nblk mismatch\n"); return -3; }
     static bool attr = false;
     if (!attr) {
+        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd1x1_fused_bf16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd1x1_fused_bf16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd1x1_fused_bf16<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     // SURVEY 8(d) strict bytes: x read once, Y written once
     ProfScope ps("k_fwd1x1_fused_bf16", 2.0 * a.M * 128.0 * a.cin, (double)a.M * 2.0 * (a.cin + 128.0), st);
     const int nblk = fwd1x1_fused_nblk(a);
-    if (a.Kp <= 256) hipLaunchKernelGGL(k_fwd1x1_fused_bf16<2>, dim3(nblk), dim3(256), FwdCfg<2>::SMEM, st, a);
-    else hipLaunchKernelGGL(k_fwd1x1_fused_bf16<4>, dim3(nblk), dim3(256), FwdCfg<4>::SMEM, st, a);
+    if (a.Kp <= 128) hipLaunchKernelGGL(k_fwd1x1_fused_bf16<1>, dim3(nblk), dim3(256), FwdCfg<1>::SMEM, st, a);
+    else hipLaunchKernelGGL(k_fwd1x1_fused_bf16<2>, dim3(nblk), dim3(256), FwdCfg<2>::SMEM, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
 }
