@@ -96,6 +96,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
     // takes longer than k_eff_mat + k_gemm_nt did (105 against ~58 us at four slices), the step is shorter without the two extra launches
     // per layer on the main stream and the TN GEMM competing on the side stream.  TCVN_BWD1_MAXCIN (validation build) restores a limit.
     static const int fuse1_maxcin = TCVN_KNOB_INT("TCVN_BWD1_MAXCIN") > 0 ? TCVN_KNOB_INT("TCVN_BWD1_MAXCIN") : (1 << 30);
+    const bool side_on = fast3x3 && !serial_env && backward_overlap_enabled();
     if (side_on && (rc = ensure_side())) return rc;
     int seq = 0;                                   // parity of the EY buffer / tail half; reset by drain()
     bool side_busy = false;
