@@ -262,7 +262,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--side-priority", type=int, default=None, help="A/B: priority of the event-embedder side stream (-1 = high)")
-    ap.add_argument("--no-bwd-overlap", action="store_true", help="A/B: keep the weight-gradient kernels on the main stream (tcvn_backward_overlap(0))")
+    ap.add_argument("--no-bwd-overlap", action="store_true", help="keep the weight-gradient kernels on the main stream (tcvn_backward_overlap(0): the library's default since round 4)")
+    ap.add_argument("--bwd-overlap", action="store_true", help="A/B: 3x3 weight gradients on the plan's side stream (tcvn_backward_overlap(1), the default of rounds 2-3)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing (fp32_ms_per_step)")
     ap.add_argument("--dump-records", default="", help="write every profiled launch (name, ms, flops) to this JSON file")
     args = ap.parse_args()
@@ -315,8 +316,7 @@ def main():
     if args.side_priority is not None:
         rt.side_priority = args.side_priority
     rt.ensure_bound()
-    if args.no_bwd_overlap:
-        _lib.lib.tcvn_backward_overlap(0)
+    _lib.lib.tcvn_backward_overlap(1 if args.bwd_overlap and not args.no_bwd_overlap else 0)
     batch = make_batch(args.batch, (1, 16) if args.ragged_inference else args.prongs, 1234 + rank, dev)
     if args.ragged_inference:
         model.eval()
@@ -355,7 +355,7 @@ def main():
         step()
         torch.cuda.synchronize()
         rt.overlap_embedders = True
-        _lib.lib.tcvn_backward_overlap(0 if args.no_bwd_overlap else 1)
+        _lib.lib.tcvn_backward_overlap(1 if args.bwd_overlap and not args.no_bwd_overlap else 0)
         if profiled:
             _lib.lib.tcvn_profile_enable(0)
             records = _lib.profile_records()

@@ -367,7 +367,7 @@ int bwd1x1_fused_nblk(const Bwd1x1Args& a) {
     return (int)(mt < cap ? mt : cap);
 }
 
-int bwd1x1_fused(const Bwd1x1Args& a, float* dWk, float* dbias, hipStream_t st) {
+int bwd1x1_fused_launch(const Bwd1x1Args& a, hipStream_t st) {
     if (a.M <= 0) return 0;
     if (!bwd1x1_fused_ok(a)) return -2;
     if (a.nblk != bwd1x1_fused_nblk(a)) { fprintf(stderr, "tcvn: bwd1x1_fused nblk mismatch\n"); return -3; }
@@ -376,12 +376,17 @@ int bwd1x1_fused(const Bwd1x1Args& a, float* dWk, float* dbias, hipStream_t st) 
         TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd1x1_fused_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    {
-        // SURVEY 8(d) strict bytes: operands DU, Y, x read once, the G contribution written once (its read is traffic, not algorithm)
-        ProfScope ps("k_bwd1x1_fused_bf16", 4.0 * a.M * 128.0 * a.cin, (double)a.M * (512.0 + 4.0 * a.cin), st);
-        hipLaunchKernelGGL(k_bwd1x1_fused_bf16, dim3(a.nblk, cdiv(a.cin, 128)), dim3(256), SMEM_BYTES, st, a);
-        TCVN_LAUNCH_CHECK();
-    }
+    // SURVEY 8(d) strict bytes: operands DU, Y, x read once, the G contribution written once (its read is traffic, not algorithm)
+    ProfScope ps("k_bwd1x1_fused_bf16", 4.0 * a.M * 128.0 * a.cin, (double)a.M * (512.0 + 4.0 * a.cin), st);
+    hipLaunchKernelGGL(k_bwd1x1_fused_bf16, dim3(a.nblk, cdiv(a.cin, 128)), dim3(256), SMEM_BYTES, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+// the launch's per-workgroup weight-gradient tiles and bias column sums -> dWk [128][ldc], dbias [128] (accumulating); any stream ordered
+// behind the launch -- nothing on the data-gradient chain waits for it
+int bwd1x1_fused_reduce(const Bwd1x1Args& a, float* dWk, float* dbias, hipStream_t st) {
+    if (a.M <= 0) return 0;
     return slab_reduce2(slab_job(a.slab, a.nblk, 128L * a.ldc, dWk, 0), slab_job(a.tail, a.nblk, 128, dbias, 0), st);
 }
 

@@ -11,10 +11,11 @@
 
 using namespace tcvn;
 
-// tcvn_backward_overlap(): ON by default since round 2.  Measured on MI355X (B=32 x 8 prongs, alternating runs): 26.0-26.1 ms with the
-// weight gradients on the side stream vs 26.4 ms without (-1.2 %).  The overlapped kernels share the CUs, which inflates the
-// per-launch times an event pair sees for them: bench.py's survey step (the per-kernel roofline leg) switches it off while it measures.
-static int g_backward_overlap = 1;
+// tcvn_backward_overlap(): the 3x3 weight gradients on a side stream beside the data-gradient chain.  ON by default in rounds 2-3 (26.0-26.1 ms
+// against 26.4 ms when the side stream also carried the 1x1 TN GEMMs).  OFF by default since round 4: with the fused 1x1 backward kernel on the
+// main stream only the 3x3 weight gradient is left to overlap, and the same-box A/B reads 19.55 ms/step serial against 19.55-19.60 with the side
+// stream (19.8 when the fused kernel's slab reductions also went there) -- nothing to gain, and serial kernel timings are what profiles show.
+static int g_backward_overlap = 0;
 bool tcvn::backward_overlap_enabled() { return g_backward_overlap != 0; }
 void tcvn::set_backward_overlap(int on) { g_backward_overlap = on; }
 
@@ -310,11 +311,13 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 fa.DU = DU; fa.Y = Y; fa.PY = PY; fa.QY = QY; fa.M = M; fa.Xin = D; fa.ldx = bg.ld; fa.cin = ls.cin;
                 fa.sc = sc_of(ls.n1); fa.sh = sh_of(ls.n1); fa.sl = data[ls.a1]; fa.Gout = G; fa.ldg = bg.ld;
                 fa.Wfrag = ws + L.wk + etf.off; fa.Kp = etf.Kp; fa.zeros = ws + L.zeros; fa.part = part;
+                // The slab reduction stays on `st` behind the launch: on the side stream (double-buffered slabs, measured) the step was 0.25 ms LONGER.
                 fa.slab = reinterpret_cast<float*>(ws + L.slab1); fa.slab_bytes = kSlabGemmBytes; fa.ldc = ef.Kp;
                 fa.tail = reinterpret_cast<float*>(ws + L.slab1 + kSlabGemmBytes);
                 fa.nblk = bwd1x1_fused_nblk(fa);
                 if (bwd1x1_fused_ok(fa)) {
-                    if ((rc = bwd1x1_fused(fa, gw_of(ls.w1), grad[ls.b1], st))) return rc;
+                    if ((rc = bwd1x1_fused_launch(fa, st))) return rc;
+                    if ((rc = bwd1x1_fused_reduce(fa, gw_of(ls.w1), grad[ls.b1], st))) return rc;
                     if ((rc = bwd_link(ls.n1, fa.nblk, bstatD, M, P, Q, 1, ls.a1))) return rc;
                     continue;
                 }

@@ -27,7 +27,8 @@ struct Layout {
     std::vector<std::vector<long>> EY3;               // bf16 mode: [pixels][32] eff rows of a layer's 3x3 output gradient (data gradient -> weight gradient)
     std::vector<std::vector<long>> KM;                // bf16 mode with dropout: one keep word per pixel and dense layer (3x3 output dropout)
     long zeros, ey, ey2, slab;
-    long slab1;                          // bf16 mode: slabs of the fused 1x1 backward kernel (main stream; `slab` belongs to the weight-gradient side stream)
+    long slab1;                          // bf16 mode: slabs of the fused 1x1 backward kernel (main stream; `slab` may be in use by the 3x3 weight gradient
+                                         // on the side stream when tcvn_backward_overlap is on)
     long sidx;                           // sparse-stem bucket index (stem_sparse.hip), -1 when the plan cannot use it
     std::vector<std::vector<long>> XA;   // activated bf16 copies of the 1x1-conv inputs (per layer, -1 if absent)
     std::vector<long> XP;                // pooled activated transition inputs (-1 if absent)

@@ -256,7 +256,8 @@ struct Bwd1x1Args {
 };
 bool bwd1x1_fused_ok(const Bwd1x1Args& a);
 int bwd1x1_fused_nblk(const Bwd1x1Args& a);
-int bwd1x1_fused(const Bwd1x1Args& a, float* dWk, float* dbias, hipStream_t st);   // + the slab reductions into dWk [128][ldc], dbias [128]
+int bwd1x1_fused_launch(const Bwd1x1Args& a, hipStream_t st);
+int bwd1x1_fused_reduce(const Bwd1x1Args& a, float* dWk, float* dbias, hipStream_t st);   // slab reductions into dWk [128][ldc], dbias [128]
 
 // Forward of a bottleneck 1x1 convolution on the RAW concat buffer (fwd1x1_fused.hip): norm1 + PReLU1 applied to the landed LDS tiles,
 // Y[m][0:128] = bf16(act(x) x W1^T + bias), statistics partials of Y -- replaces act_bf16 + gemm_nt_bf16<EPI_FWD> of a dense layer.

@@ -134,7 +134,10 @@ loss_local, g_local = step(False, o_local)
 expected = g_local.clone()
 dist.all_reduce(expected)                               # blocking SUM of the two LOCAL gradients
 expected /= 2
+from transformercvn.hip._lib import lib as _tl
+_tl.tcvn_backward_overlap(1)                            # the exchange step runs with the library's weight-gradient side stream ON (off by default since round 4)
 loss_dp, g_dp = step(True, o_dp)
+_tl.tcvn_backward_overlap(0)
 n_blocks = len(cfg.densenet_structure)
 want = ["head", "event"] + [f"prong{i}" for i in range(n_blocks - 1, -1, -1)]
 assert o_dp == want and o_local == want, (o_dp, o_local)
