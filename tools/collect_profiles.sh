@@ -3,7 +3,7 @@
 #   bash tools/collect_profiles.sh r02
 # Everything lands in gpurun_out/<tag>final/; copy what is to be judged into profiles/.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${TAG}final
 mkdir -p $OUT

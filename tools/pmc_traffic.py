@@ -13,12 +13,14 @@ import json
 import sys
 
 LABELS = {            # bench.py label -> substring of the demangled kernel name
+    "k_bwd1x1_fused_bf16": "k_bwd1x1_fused_bf16",
+    "k_fwd1x1_fused_bf16": "k_fwd1x1_fused_bf16",
     "k_gemm_nt_bf16<dgrad1x1>": "k_gemm_nt_bf16<1, ",
     "k_gemm_nt_bf16<dgradtrans>": "k_gemm_nt_bf16<2, ",
     "k_conv3x3_dgrad_bf16": "k_conv3x3_dgrad",
     "k_conv3x3_fwd_bf16": "k_conv3x3_fwd_",
     "k_conv3x3_wgrad_bf16": "k_conv3x3_wgrad_bf16",
-    "k_stem_fwd_bf16": "k_stem_fwd_bf16",
+    "k_stem_fwd_bf16": "k_stem_fwd2_bf16",
     "k_act_bf16": "k_act_bf16",
     "k_eff_mat": "k_eff_mat",
     "k_gemm_tn_bf16<conv1>": "k_gemm_tn_bf16<0>",
