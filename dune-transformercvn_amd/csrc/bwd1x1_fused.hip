@@ -385,9 +385,11 @@ int bwd1x1_fused_launch(const Bwd1x1Args& a, hipStream_t st) {
 
 // the launch's per-workgroup weight-gradient tiles and bias column sums -> dWk [128][ldc], dbias [128] (accumulating); any stream ordered
 // behind the launch -- nothing on the data-gradient chain waits for it
-int bwd1x1_fused_reduce(const Bwd1x1Args& a, float* dWk, float* dbias, hipStream_t st) {
-    if (a.M <= 0) return 0;
-    return slab_reduce2(slab_job(a.slab, a.nblk, 128L * a.ldc, dWk, 0), slab_job(a.tail, a.nblk, 128, dbias, 0), st);
+int bwd1x1_fused_reduce(const Bwd1x1Args& a, float* dWk, float* dbias, const SlabJob* extra, hipStream_t st) {
+    SlabJob jobs[4] = {};
+    if (a.M > 0) { jobs[0] = slab_job(a.slab, a.nblk, 128L * a.ldc, dWk, 0); jobs[1] = slab_job(a.tail, a.nblk, 128, dbias, 0); }
+    if (extra != nullptr) { jobs[2] = extra[0]; jobs[3] = extra[1]; }          // e.g. the same layer's 3x3 weight-gradient slabs: one launch for both
+    return slab_reduce4(jobs, 4, st);
 }
 
 }  // namespace tcvn

@@ -1726,6 +1726,7 @@ int conv3x3_wgrad_tile(const ConvWgradArgs& a, hipStream_t st) {
     // weight partials [nb][9*128*32] -> dWk and bias partials [nb][32] -> dbias[0:N) (32-wide rows, zero beyond N): one launch
     SlabJob jb{};
     if (a.dbias != nullptr) jb = slab_job(a.slab + (long)nb * (9 * 128 * 32), nb, a.e.N, a.dbias, 32);
+    if (a.deferred != nullptr) { a.deferred[0] = slab_job(a.slab, nb, 9 * 128 * 32, a.dWk, 0); a.deferred[1] = jb; return 0; }
     return slab_reduce2(slab_job(a.slab, nb, 9 * 128 * 32, a.dWk, 0), jb, st);
 }
 

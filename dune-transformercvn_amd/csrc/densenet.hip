@@ -130,6 +130,7 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
     L.c0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
     L.D.clear(); L.Y.clear(); L.bstatD.clear(); L.bstatY.clear(); L.YA.clear(); L.XA.clear(); L.XP.clear(); L.KM.clear();
     L.zeros = b.take(1024);
+    L.sact = (cfg.mode == MODE_BF16 && cfg.init_ch == 64) ? b.take((long)n * Hc * stem_act_words(Wc) * 4) : -1;
     L.sidx = sparse_stem_possible() ? b.take(stem_sparse_index_bytes(n, cfg.H, cfg.W)) : -1;
     long max_part = (long)pool0_grid(n, blocks[0].H, blocks[0].W) * cfg.init_ch * 16;
     max_part = std::max(max_part, 1024L * cfg.init_ch * 16);      // sparse stem passes: <= 1024 workgroups
@@ -390,6 +391,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
     const bool sparse_stem = !dense_stem_knob && (!train || sparse_train_knob) && L.sidx >= 0 &&
                              stem_sparse_ok(mode, cfg.in_ch, cfg.init_ch, cfg.H, cfg.W, log_pixels, nnz, n, blocks[0].ld);
     last_sparse_stem = sparse_stem;
+    last_stem_act = false;
     last_fused_ya = false;
     last_values = values; last_value_mode = log_pixels; last_noise = train ? noise_std : 0.f;
     int init_nblk = 0, init_ld = cfg.init_ch;
@@ -419,13 +421,31 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         if ((rc = scatter_pixels(a, st))) return rc;
     }
     const long M0 = (long)n * Hc * Wc;
+    // Round 4: the maps are mostly empty, so most conv0 outputs are exactly bf16(bias).  A bitmap of the positions some hit reaches
+    // (stem_mark) lets conv0 skip the stores of all other rows and the pooling kernels (forward and backward) read one shared row for them:
+    // with 20-800 hits per prong map ~16 % of the 28 000 positions per map are touched, i.e. the conv0 output and its gradient (0.9 GB each at
+    // 256 maps) shrink to the lines that carry information.  Dense addressing is kept (a row is exactly one 128-B line), results are bit-identical.
+    static const bool no_stem_skip = TCVN_KNOB_SET("TCVN_NO_STEM_SKIP");
+    uint32_t* sact = nullptr;
+    const void* cline = ws + L.zeros + 512;                 // the zero page is 1 KB; DMA sources use its first 256 B
+    {
+        const WkEntry& e0 = wk_find(s_w0, 0);
+        ConvFwdArgs probe{};
+        probe.mode = mode; probe.amode = A_STEM; probe.M = (int)M0; probe.N = cfg.init_ch; probe.K = 49 * cfg.in_ch; probe.Kp = e0.Kp; probe.C = cfg.in_ch;
+        probe.H = Hc; probe.W = Wc; probe.Hin = cfg.H; probe.Win = cfg.W; probe.ldo = cfg.init_ch; probe.n_off = 0; probe.Out = ws + L.c0;
+        if (!no_stem_skip && L.sact >= 0 && stem_fwd_ok(probe) && (blocks[0].ld & 7) == 0 && coords != nullptr) {
+            sact = reinterpret_cast<uint32_t*>(ws + L.sact);
+            if ((rc = stem_mark(coords, nnz, n, cfg.H, cfg.W, Hc, Wc, sact, data[s_b0], const_cast<void*>(cline), st))) return rc;
+        }
+    }
+    last_stem_act = sact != nullptr;
     {
         const WkEntry& e = wk_find(s_w0, 0);
         ConvFwdArgs a{};
         a.mode = mode; a.amode = A_STEM; a.A = ws + L.img; a.lda = cfg.in_ch; a.M = (int)M0; a.N = cfg.init_ch;
         a.K = 49 * cfg.in_ch; a.Kp = e.Kp; a.C = cfg.in_ch; a.H = Hc; a.W = Wc; a.Hin = cfg.H; a.Win = cfg.W;
         a.Wk = ws + L.wk + e.off; a.bias = data[s_b0]; a.Out = ws + L.c0; a.ldo = cfg.init_ch; a.n_off = 0;
-        a.part = train ? part : nullptr; a.nblk = conv_fwd_nblk(a);
+        a.part = train ? part : nullptr; a.nblk = conv_fwd_nblk(a); a.stem_act = sact;
         if ((rc = conv_fwd(a, st))) return rc;
         if ((rc = link(n0, part, a.nblk, cfg.init_ch, 0, cfg.init_ch, reinterpret_cast<double*>(ws + L.bstat0), M0))) return rc;
     }
@@ -433,7 +453,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         const BlockGeom& b0 = blocks[0];
         Tab t = tab(n0);
         Pool0Args a{mode, ws + L.c0, n, Hc, Wc, cfg.init_ch, t.sc, t.sh, data[s_a0], ws + L.D[0], b0.ld, b0.H, b0.W,
-                    train ? part : nullptr, pool0_grid(n, b0.H, b0.W)};
+                    train ? part : nullptr, pool0_grid(n, b0.H, b0.W), sact, cline};
         if ((rc = pool0_fwd(a, st))) return rc;
     }
     init_nblk = pool0_grid(n, blocks[0].H, blocks[0].W);

@@ -278,6 +278,24 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 if ((rc = conv_dgrad(d, st))) return rc;
                 if ((rc = bwd_link(ls.n2, d.nblk, reinterpret_cast<const double*>(ws + L.bstatY[bi][l]), M, PY, QY, 0, ls.a2))) return rc;
             }
+            // Fused 1x1 backward (round 4, bwd1x1_fused.hip): effective gradient formed in LDS, bias / data / weight gradient and the norm1
+            // backward epilogue in one pass -- no EY in HBM, no read of the activated copy XA, one launch instead of three.  It writes G, so it
+            // runs on `st`; its slabs are its own (L.slab belongs to the 3x3 weight gradient, which may be on the side stream).
+            const bool xa_absent = bi < (int)xa_skipped.size() && l < (int)xa_skipped[bi].size() && xa_skipped[bi][l];
+            Bwd1x1Args fa{};
+            bool fuse1 = L.XA[bi][l] >= 0 && !no_fuse1 && mid == 128 && L.slab1 >= 0 && (ls.cin <= fuse1_maxcin || xa_absent);
+            if (fuse1) {
+                const WkEntry& etf = wk_find(ls.w1, 1, 1);
+                fa.DU = DU; fa.Y = Y; fa.PY = PY; fa.QY = QY; fa.M = M; fa.Xin = D; fa.ldx = bg.ld; fa.cin = ls.cin;
+                fa.sc = sc_of(ls.n1); fa.sh = sh_of(ls.n1); fa.sl = data[ls.a1]; fa.Gout = G; fa.ldg = bg.ld;
+                fa.Wfrag = ws + L.wk + etf.off; fa.Kp = etf.Kp; fa.zeros = ws + L.zeros; fa.part = part;
+                fa.slab = reinterpret_cast<float*>(ws + L.slab1); fa.slab_bytes = kSlabGemmBytes; fa.ldc = wk_find(ls.w1, 0).Kp;
+                fa.tail = reinterpret_cast<float*>(ws + L.slab1 + kSlabGemmBytes);
+                fa.nblk = bwd1x1_fused_nblk(fa);
+                fuse1 = bwd1x1_fused_ok(fa);
+            }
+            SlabJob w3jobs[2] = {};        // the 3x3 weight gradient's slab reductions, folded into the fused kernel's reduction launch (same stream only)
+            bool w3_deferred = false;
             {   // conv2 (3x3) weight gradient: beside the rest of this layer's data-gradient chain
                 const WkEntry& ef = wk_find(ls.w2, 0);
                 ConvWgradArgs w{};
@@ -297,30 +315,17 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                     TCVN_CHECK(hipStreamWaitEvent(side_st, ev_fork_a, 0));
                     side_busy = true;
                 }
+                if (!par && fuse1 && fast3x3 && conv3x3_wgrad_tile_ok(w)) { w.deferred = w3jobs; w3_deferred = true; }
                 if ((rc = conv_wgrad(w, par ? side_st : st))) return rc;
             }
             EffSrc e1{DU, mid, Y, mid, 0, mid, PY, QY, 0.f, 0, 0};
-            const bool xa_absent = bi < (int)xa_skipped.size() && l < (int)xa_skipped[bi].size() && xa_skipped[bi][l];
-            if (L.XA[bi][l] >= 0 && !no_fuse1 && mid == 128 && L.slab1 >= 0 && (ls.cin <= fuse1_maxcin || xa_absent)) {
-                // Fused 1x1 backward (round 4, bwd1x1_fused.hip): effective gradient formed in LDS, bias / data / weight gradient and the norm1
-                // backward epilogue in one pass -- no EY in HBM, no read of the activated copy XA, one launch (+ its slab reduction) instead
-                // of three (+ one).  It writes G, so it runs on `st`; its slabs are its own (the 3x3 weight gradient on the side stream owns L.slab).
-                const WkEntry& etf = wk_find(ls.w1, 1, 1);
-                const WkEntry& ef = wk_find(ls.w1, 0);
-                Bwd1x1Args fa{};
-                fa.DU = DU; fa.Y = Y; fa.PY = PY; fa.QY = QY; fa.M = M; fa.Xin = D; fa.ldx = bg.ld; fa.cin = ls.cin;
-                fa.sc = sc_of(ls.n1); fa.sh = sh_of(ls.n1); fa.sl = data[ls.a1]; fa.Gout = G; fa.ldg = bg.ld;
-                fa.Wfrag = ws + L.wk + etf.off; fa.Kp = etf.Kp; fa.zeros = ws + L.zeros; fa.part = part;
-                // The slab reduction stays on `st` behind the launch: on the side stream (double-buffered slabs, measured) the step was 0.25 ms LONGER.
-                fa.slab = reinterpret_cast<float*>(ws + L.slab1); fa.slab_bytes = kSlabGemmBytes; fa.ldc = ef.Kp;
-                fa.tail = reinterpret_cast<float*>(ws + L.slab1 + kSlabGemmBytes);
-                fa.nblk = bwd1x1_fused_nblk(fa);
-                if (bwd1x1_fused_ok(fa)) {
-                    if ((rc = bwd1x1_fused_launch(fa, st))) return rc;
-                    if ((rc = bwd1x1_fused_reduce(fa, gw_of(ls.w1), grad[ls.b1], st))) return rc;
-                    if ((rc = bwd_link(ls.n1, fa.nblk, bstatD, M, P, Q, 1, ls.a1))) return rc;
-                    continue;
-                }
+            if (fuse1) {
+                // The slab reductions stay on `st` behind the launch (on the side stream, with double-buffered slabs, the step was 0.25 ms LONGER);
+                // one launch reduces this kernel's slabs and the 3x3 weight gradient's.
+                if ((rc = bwd1x1_fused_launch(fa, st))) return rc;
+                if ((rc = bwd1x1_fused_reduce(fa, gw_of(ls.w1), grad[ls.b1], w3_deferred ? w3jobs : nullptr, st))) return rc;
+                if ((rc = bwd_link(ls.n1, fa.nblk, bstatD, M, P, Q, 1, ls.a1))) return rc;
+                continue;
             }
             if (bi < (int)xa_skipped.size() && l < (int)xa_skipped[bi].size() && xa_skipped[bi][l]) {
                 fprintf(stderr, "tcvn: the forward skipped the activated 1x1 input of block %d layer %d but the fused 1x1 backward cannot run\n", bi, l);
@@ -405,8 +410,12 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             if ((rc = stem_sparse_bwd(sa, 1, st))) return rc;
         } else {
         Pool0BwdArgs a{mode, ws + L.c0, n, Hc, Wc, cfg.init_ch, sc_of(n0), sh_of(n0), data[s_a0], e, b0.H, b0.W, ws + L.du0, part,
-                       pool0_bwd_grid(n, Hc, Wc)};
+                       pool0_bwd_grid(n, Hc, Wc), nullptr, nullptr};
+        if (last_stem_act) {                     // the forward skipped the conv0-output rows no hit reaches: read the shared row for them, skip their gradient rows
+            a.act = reinterpret_cast<const uint32_t*>(ws + L.sact); a.cline = ws + L.zeros + 512;
+        }
         const bool vec = pool0_bwd_vec_ok(a) && conv3x3_tile_enabled();
+        if (last_stem_act && !(vec && cfg.init_ch == 64 && mode == MODE_BF16)) { fprintf(stderr, "tcvn: stem activity bitmap without the tile kernel\n"); return -16; }
         if (vec) { a.nblk = pool0_bwd_vec_grid(n, Hc, Wc); rc = pool0_bwd_vec(a, st); }
         else rc = pool0_bwd(a, st);
         if (rc) return rc;

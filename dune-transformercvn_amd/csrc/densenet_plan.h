@@ -29,6 +29,7 @@ struct Layout {
     long zeros, ey, ey2, slab;
     long slab1;                          // bf16 mode: slabs of the fused 1x1 backward kernel (main stream; `slab` may be in use by the 3x3 weight gradient
                                          // on the side stream when tcvn_backward_overlap is on)
+    long sact;                           // bf16 dense stem: activity bitmap of the conv0 output (stem_mark), -1 when unused
     long sidx;                           // sparse-stem bucket index (stem_sparse.hip), -1 when the plan cannot use it
     std::vector<std::vector<long>> XA;   // activated bf16 copies of the 1x1-conv inputs (per layer, -1 if absent)
     std::vector<long> XP;                // pooled activated transition inputs (-1 if absent)
@@ -66,6 +67,7 @@ struct DenseNetPlan {
     std::vector<std::vector<char>> xa_skipped;   // [block][layer]: the last forward ran the fused 1x1 kernel on the raw concat buffer: no activated copy XA of that
                                                  // layer's input exists, backward must take the fused 1x1 kernel (which rebuilds it from x)
     bool last_fused_ya = false;          // the last forward was an eval pass whose 1x1 GEMMs wrote the activated bottleneck maps only (no raw Y)
+    bool last_stem_act = false;          // the last forward's dense stem skipped the conv0-output rows no hit reaches (backward must use the same bitmap)
     bool last_sparse_stem = false;       // the last forward ran the sparse-aware stem: no dense map / conv0 output exists (backward must match)
     bool sparse_stem_possible() const;   // plan-level condition (bf16, 3 -> 64 channels); the hit count decides per call
     // weight-gradient side stream of backward (3x3 and 1x1 weight gradients run beside the data-gradient chain)

@@ -184,8 +184,9 @@ __global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a, int wlog) {
 // dst[i] += sum_s slab[s*stride + i]: block = 64 columns x 4 slab lanes; grid.y splits the slabs (<= 16 atomics per element);
 // grid.z selects one of two independent jobs (e.g. a weight-gradient slab and the bias column sums of the same layer: one
 // launch instead of two -- these launches sit at the ~5 us dispatch floor)
-__global__ __launch_bounds__(256) void k_slab_reduce(const SlabJob j0, const SlabJob j1) {
-    const SlabJob& j = blockIdx.z == 0 ? j0 : j1;
+__global__ __launch_bounds__(256) void k_slab_reduce(const SlabJob j0, const SlabJob j1, const SlabJob j2, const SlabJob j3) {
+    const SlabJob& j = blockIdx.z == 0 ? j0 : blockIdx.z == 1 ? j1 : blockIdx.z == 2 ? j2 : j3;
+    if (j.count <= 0) return;
     __shared__ __attribute__((aligned(16))) float red[4][256];
     const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
     if ((int)blockIdx.y >= j.ny) return;                                               // uniform per workgroup
@@ -306,13 +307,24 @@ SlabJob slab_job(const float* slab, int nslab, long count, float* dst, long stri
     j.ny = ny; j.per_y = cdiv(nslab, ny);
     return j;
 }
-int slab_reduce2(const SlabJob& a, const SlabJob& b, hipStream_t st) {
-    if (a.count <= 0 && b.count <= 0) return 0;
-    const long ga = a.count > 0 ? cdiv(a.count, a.v4 ? 256 : 64) : 0, gb = b.count > 0 ? cdiv(b.count, b.v4 ? 256 : 64) : 0;
-    const int nymax = a.ny > b.ny ? a.ny : b.ny;
-    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)(ga > gb ? ga : gb), nymax, b.count > 0 ? 2 : 1), dim3(256), 0, st, a, b);
+// up to four independent jobs in one launch (grid.z); empty jobs (count == 0) are skipped
+int slab_reduce4(const SlabJob* jobs, int n, hipStream_t st) {
+    SlabJob j[4] = {};
+    long gmax = 0; int nymax = 1, nz = 0;
+    for (int i = 0; i < n && i < 4; ++i) {
+        if (jobs[i].count <= 0) continue;
+        j[nz++] = jobs[i];
+        const long g = cdiv(jobs[i].count, jobs[i].v4 ? 256 : 64);
+        gmax = g > gmax ? g : gmax; nymax = jobs[i].ny > nymax ? jobs[i].ny : nymax;
+    }
+    if (nz == 0) return 0;
+    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)gmax, nymax, nz), dim3(256), 0, st, j[0], j[1], j[2], j[3]);
     TCVN_LAUNCH_CHECK();
     return 0;
+}
+int slab_reduce2(const SlabJob& a, const SlabJob& b, hipStream_t st) {
+    const SlabJob jobs[2] = {a, b};
+    return slab_reduce4(jobs, 2, st);
 }
 int slab_reduce(const float* slab, int nslab, long count, float* dst, hipStream_t st, long stride) {
     SlabJob none{};

@@ -13,6 +13,28 @@ namespace tcvn {
 
 namespace {
 
+// ---- activity bitmap of the conv0 output (see stem_mark in tcvn_ops.h): one thread per hit ------------------------------------------------
+__global__ void k_stem_mark(const int* __restrict__ coords, long nnz, int n_img, int H, int W, int Hc, int Wc, int WW, uint32_t* __restrict__ act,
+                            const float* __restrict__ bias, bf16* __restrict__ cline) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 64) cline[threadIdx.x] = f2bf(bias[threadIdx.x]);     // the row of a position no hit reaches: bf16(0 + bias)
+    if (i >= nnz) return;
+    const int img = coords[i * 3], y = coords[i * 3 + 1], x = coords[i * 3 + 2];
+    if (img < 0 || img >= n_img || y < 0 || y >= H || x < 0 || x >= W) return;                 // k_scatter drops the same hits
+    // output (oy, ox) reads input rows 2*oy - 3 .. 2*oy + 3: ceil((y - 3) / 2) <= oy <= floor((y + 3) / 2)
+    const int oy0 = max(0, (y - 2) >> 1), oy1 = min(Hc - 1, (y + 3) >> 1);
+    const int ox0 = max(0, (x - 2) >> 1), ox1 = min(Wc - 1, (x + 3) >> 1);
+    if (ox0 > ox1) return;
+    const int w0 = ox0 >> 5, w1 = ox1 >> 5;
+    const uint32_t m_lo = (w0 == w1 ? ((ox1 - ox0 + 1 >= 32) ? 0xffffffffu : ((1u << (ox1 - ox0 + 1)) - 1u)) : 0xffffffffu) << (ox0 & 31);
+    const uint32_t m_hi = w0 == w1 ? 0u : (0xffffffffu >> (31 - (ox1 & 31)));
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        uint32_t* row = act + ((long)img * Hc + oy) * WW;
+        atomicOr(row + w0, m_lo);
+        if (m_hi) atomicOr(row + w1, m_hi);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pool0_bwd_vec(const Pool0BwdArgs a) {
     __shared__ double red[4][8][8][3];
     const bf16* X = reinterpret_cast<const bf16*>(a.X);
@@ -194,6 +216,8 @@ __global__ __launch_bounds__(256, 2) void k_pool0_bwd_tile(const Pool0BwdArgs a,
     // per-channel tables live in LDS and are re-read where they are used (a phase needs 16-24 of the 40 values: keeping all of them
     // and fp64 running sums in registers next to a 2x2 block's 64 operand registers would halve the occupancy)
     __shared__ __attribute__((aligned(16))) float tabs[5][64];
+    __shared__ uint32_t actw[PB_TH];                                       // activity word of each tile row (PB_TW == 32: one word per row and tile)
+    const int WW = (a.Win + 31) >> 5;
     if (tid < 64) { tabs[0][tid] = a.sc[tid]; tabs[1][tid] = a.sh[tid]; tabs[2][tid] = a.sl[tid]; tabs[3][tid] = a.e.P[tid]; tabs[4][tid] = a.e.Q[tid]; }
     auto tab8 = [&](int which, float (&v)[8]) {
         const float4 x0 = *reinterpret_cast<const float4*>(&tabs[which][c8 * 8]), x1 = *reinterpret_cast<const float4*>(&tabs[which][c8 * 8 + 4]);
@@ -209,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void k_pool0_bwd_tile(const Pool0BwdArgs a,
         const long img = tile / ((long)tiles_x * tiles_y);
         const int h0 = ty * PB_TH, w0 = tx * PB_TW, ho0 = h0 / 2 - 1, wo0 = w0 / 2 - 1;
         __syncthreads();                                                   // previous tile's readers are done with effs
+        if (tid < PB_TH) actw[tid] = (a.act != nullptr && h0 + tid < a.Hin) ? a.act[(img * a.Hin + h0 + tid) * WW + tx] : 0xffffffffu;
         {                                                                   // eff of the pooled pixels (zero outside the map)
             constexpr int NP1 = (PB_PH * PB_PW * 8 + 255) / 256;           // 3 trips: all their loads are requested before the first use
             float gv[NP1][8], dv[NP1][8];
@@ -245,13 +270,16 @@ __global__ __launch_bounds__(256, 2) void k_pool0_bwd_tile(const Pool0BwdArgs a,
             const int bi = (tid >> 3) + 32 * k, by = bi / (PB_TW / 2), bx = bi - by * (PB_TW / 2);
             const int h = h0 + 2 * by, w = w0 + 2 * bx;
             float xv[4][8];
-            bool ok[4];
+            bool ok[4], live[4];
+            const uint32_t aw0 = actw[2 * by] >> (2 * bx), aw1 = actw[2 * by + 1] >> (2 * bx);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int hh = h + (t >> 1), ww = w + (t & 1);
                 ok[t] = (hh < a.Hin) & (ww < a.Win);
+                live[t] = ok[t] & ((((t >> 1) ? aw1 : aw0) >> (t & 1)) & 1u);                          // a hit reaches this position: its rows exist
                 const long p = ok[t] ? (img * a.Hin + hh) * a.Win + ww : img * a.Hin * a.Win;       // clamped: the load is unconditional
-                load8<T>(X + p * a.C + c8 * 8, xv[t]);
+                const T* src = (a.act == nullptr || live[t]) ? X + p * a.C + c8 * 8 : reinterpret_cast<const T*>(a.cline) + c8 * 8;
+                load8<T>(src, xv[t]);
             }
             float e[4][8], sc[8], sh[8], sl[8];
             tab8(0, sc); tab8(1, sh); tab8(2, sl);
@@ -275,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_pool0_bwd_tile(const Pool0BwdArgs a,
                     s1[j] += du; s2[j] = fmaf(du, x, s2[j]); s3[j] += u > 0.f ? 0.f : z * u;
                     o[j] = sc[j] * du;
                 }
-                if (ok[t]) store8_g<T>(DU + ((img * a.Hin + h + (t >> 1)) * a.Win + w + (t & 1)) * a.C + c8 * 8, o);
+                if (live[t]) store8_g<T>(DU + ((img * a.Hin + h + (t >> 1)) * a.Win + w + (t & 1)) * a.C + c8 * 8, o);
             }
         }
     }
@@ -566,7 +594,10 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd2_bf16(const ConvFwdArgs g, 
         for (int k = 0; k < 4; ++k) {
             const int idx = tid + 256 * k, p = idx >> 3, c8 = idx & 7;
             const int py = p >> 4, px = p & 15;
-            if ((oy0 + py < Ho) & (ox0 + px < Wo))
+            bool st_ok = (oy0 + py < Ho) & (ox0 + px < Wo);
+            if (st_ok && g.stem_act != nullptr)                              // rows of positions no hit reaches are not stored (they hold bf16(bias): cline)
+                st_ok = (g.stem_act[(n * Ho + oy0 + py) * (long)((Wo + 31) >> 5) + ((ox0 + px) >> 5)] >> ((ox0 + px) & 31)) & 1u;
+            if (st_ok)
                 *reinterpret_cast<u16x8*>(Out + ((n * Ho + oy0 + py) * (long)Wo + ox0 + px) * g.ldo + c8 * 8) =
                     *reinterpret_cast<const u16x8*>(&ctile[p * ST_CP + c8 * 8]);
         }
@@ -619,6 +650,14 @@ int pool0_bwd_vec(const Pool0BwdArgs& a, hipStream_t st) {
         return 0;
     }
     hipLaunchKernelGGL(k_pool0_bwd_vec, dim3(a.nblk), dim3(256), 0, st, a);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+
+int stem_mark(const int* coords, long nnz, int n_img, int H, int W, int Hc, int Wc, uint32_t* act, const float* bias, void* cline, hipStream_t st) {
+    const int WW = stem_act_words(Wc);
+    TCVN_CHECK(hipMemsetAsync(act, 0, (size_t)n_img * Hc * WW * 4, st));
+    hipLaunchKernelGGL(k_stem_mark, dim3(cdiv(nnz > 0 ? nnz : 1, 256)), dim3(256), 0, st, coords, nnz, n_img, H, W, Hc, Wc, WW, act, bias, reinterpret_cast<bf16*>(cline));
     TCVN_LAUNCH_CHECK();
     return 0;
 }

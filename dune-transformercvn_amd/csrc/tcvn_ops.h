@@ -30,6 +30,7 @@ struct ConvFwdArgs {
     double* part; int nblk;          // [nblk][N][2]; nblk = grid.x
     float drop_p; uint64_t seed; uint32_t stream_id;
     uint32_t* keep_out;              // optional [M]: the 3x3 pair kernel stores the keep flags of a pixel's N <= 32 channels as one word
+    const uint32_t* stem_act;        // optional (bf16 conv0 kernel): activity bitmap of the output map (StemActivity); rows of positions no hit reaches are NOT stored
     int act_fused;                   // bf16 3x3 tile kernels (forward pair kernel, weight gradient): Aact is the RAW [pixels][128] map; the wave that
                                      // fetched a row applies prelu(sc*x + sh, sl) to it in LDS, once, before any tap reads it -- no activated copy in HBM
 };
@@ -80,6 +81,7 @@ int scatter_pixels(const ScatterArgs& a, hipStream_t st);
 struct Pool0Args {
     int mode; const void* X; int n_img, Hin, Win, C; const float *sc, *sh, *sl;
     void* Out; long ldo; int Ho, Wo; double* part; int nblk;
+    const uint32_t* act; const void* cline;      // optional (bf16, C == 64): StemActivity bitmap of X and the row every inactive position holds
 };
 int pool0_fwd(const Pool0Args& a, hipStream_t st);
 int pool0_grid(int n_img, int Ho, int Wo);
@@ -139,6 +141,8 @@ bool conv3x3_dgrad_tile_ok(const ConvDgradArgs& a);
 int conv3x3_dgrad_tile_nblk(const ConvDgradArgs& a);
 int conv3x3_dgrad_tile(const ConvDgradArgs& a, hipStream_t st);
 
+// one reduction job: dst[i] += sum_{s < nslab} slab[s*stride + i], i < count
+struct SlabJob { const float* slab; float* dst; int nslab; long count, stride; int ny, per_y; int v4; };   // v4: 16-B loads (count, stride multiples of 4, 16-B aligned)
 // dWk[n][k] += sum_m eff(m, n) * a(m, k)   (a = the forward A operand, regenerated), dbias[n] += sum_m eff(m, n)
 struct ConvWgradArgs {
     int mode;
@@ -147,6 +151,8 @@ struct ConvWgradArgs {
     float* dWk; float* dbias;
     float* slab; long slab_bytes;   // scratch for per-workgroup partial gradients (padded-tile kernel)
     int nfast;        // 1: dWk is laid out [k][32] (out-channel fastest) and the padded-tile kernel must be used (bf16 3x3)
+    SlabJob* deferred;   // optional [2] (padded-tile kernel): its slab reductions (weights, bias) are returned as jobs instead of being launched --
+                         // the caller folds them into a later reduction launch; the slab must stay untouched until then
 };
 int conv_wgrad(const ConvWgradArgs& a, hipStream_t st);
 bool conv3x3_wgrad_tile_ok(const ConvWgradArgs& a);
@@ -192,15 +198,15 @@ struct Pool0BwdArgs {
     int mode; const void* X; int n_img, Hin, Win, C; const float *sc, *sh, *sl;   // X = conv0 output
     EffSrc e; int Ho, Wo;                                                          // gradient of the pooled map
     void* DU; double* part; int nblk;
+    const uint32_t* act; const void* cline;      // optional (bf16 tile kernel): inactive positions read `cline` instead of X and their DU rows are not stored
 };
 int pool0_bwd(const Pool0BwdArgs& a, hipStream_t st);
 int pool0_bwd_grid(int n_img, int Hin, int Win);
 
 // bf16 TN GEMM over pixels (gemm_tn.hip): C[i][j] += sum_m L[m][i] * R[m][j]
-// one reduction job: dst[i] += sum_{s < nslab} slab[s*stride + i], i < count
-struct SlabJob { const float* slab; float* dst; int nslab; long count, stride; int ny, per_y; int v4; };   // v4: 16-B loads (count, stride multiples of 4, 16-B aligned)
 SlabJob slab_job(const float* slab, int nslab, long count, float* dst, long stride);
 int slab_reduce2(const SlabJob& a, const SlabJob& b, hipStream_t st);          // two independent jobs in one launch (b may be empty)
+int slab_reduce4(const SlabJob* jobs, int n, hipStream_t st);                  // up to four; empty jobs are skipped
 struct GemmTnArgs { const void* L; long ldl; int Li; const void* R; long ldr; int Rj; long M; float* C; long ldc; const void* zeros;
                     float* slab; long slab_bytes;        // slab: scratch for per-slice partial tiles (no contended atomics)
                     int Ci;                              // rows of C written (<= Li; L columns in [Ci, Li) are zero padding)
@@ -257,7 +263,8 @@ struct Bwd1x1Args {
 bool bwd1x1_fused_ok(const Bwd1x1Args& a);
 int bwd1x1_fused_nblk(const Bwd1x1Args& a);
 int bwd1x1_fused_launch(const Bwd1x1Args& a, hipStream_t st);
-int bwd1x1_fused_reduce(const Bwd1x1Args& a, float* dWk, float* dbias, hipStream_t st);   // slab reductions into dWk [128][ldc], dbias [128]
+int bwd1x1_fused_reduce(const Bwd1x1Args& a, float* dWk, float* dbias, const SlabJob* extra, hipStream_t st);   // slab reductions into dWk [128][ldc], dbias [128]
+                                                                                                  // (+ up to two more jobs in the same launch)
 
 // Forward of a bottleneck 1x1 convolution on the RAW concat buffer (fwd1x1_fused.hip): norm1 + PReLU1 applied to the landed LDS tiles,
 // Y[m][0:128] = bf16(act(x) x W1^T + bias), statistics partials of Y -- replaces act_bf16 + gemm_nt_bf16<EPI_FWD> of a dense layer.
@@ -286,6 +293,11 @@ int act_pool_bf16(const ActPoolArgs& a, hipStream_t st);
 int act_pool_f32(const ActPoolArgs& a, hipStream_t st);      // fp32 operands; C % 4 == 0; columns [C, ldo) := 0
 
 // bf16 stem kernels (stem.hip)
+// Activity of the conv0 output map: bit (img, oy, ox) is set when at least one hit of the COO list lies in the 7x7 / stride-2 window of output
+// position (oy, ox).  Every other position holds exactly bf16(bias) (a sum of zeros plus the bias) -- the dense stem kernels neither store nor
+// load those rows (conv0 output, its gradient): they read one shared 128-B row `cline` instead.  Words per map row: stem_act_words(Wc).
+inline int stem_act_words(int Wc) { return (Wc + 31) >> 5; }
+int stem_mark(const int* coords, long nnz, int n_img, int H, int W, int Hc, int Wc, uint32_t* act, const float* bias, void* cline, hipStream_t st);
 int pool0_bwd_vec_grid(int n_img, int Hin, int Win);
 bool pool0_bwd_vec_ok(const Pool0BwdArgs& a);
 int pool0_bwd_vec(const Pool0BwdArgs& a, hipStream_t st);
