@@ -421,11 +421,13 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         if ((rc = scatter_pixels(a, st))) return rc;
     }
     const long M0 = (long)n * Hc * Wc;
-    // Round 4: the maps are mostly empty, so most conv0 outputs are exactly bf16(bias).  A bitmap of the positions some hit reaches
-    // (stem_mark) lets conv0 skip the stores of all other rows and the pooling kernels (forward and backward) read one shared row for them:
-    // with 20-800 hits per prong map ~16 % of the 28 000 positions per map are touched, i.e. the conv0 output and its gradient (0.9 GB each at
-    // 256 maps) shrink to the lines that carry information.  Dense addressing is kept (a row is exactly one 128-B line), results are bit-identical.
-    static const bool no_stem_skip = TCVN_KNOB_SET("TCVN_NO_STEM_SKIP");
+    // Round 4: the maps are mostly empty, so most conv0 outputs are exactly bf16(bias) (a sum of zeros plus the bias).  stem_mark builds a bitmap
+    // of the output positions some hit reaches (~16 % of a prong map's 28 000 at 20-800 hits); the pooling BACKWARD kernel reads one shared row for
+    // every other position and does not store their gradient rows (only the hit-list weight gradient reads that tensor).  Bit-identical results.
+    // Measured and NOT kept: the same bitmap in conv0 (stores skipped) and in the forward pooling kernel -- the forward pooling got slower
+    // (prong embedder 271 -> 345 us: its nine loads per pixel turn into a mix of L2 hits and isolated 128-B HBM lines, which DRAM serves far
+    // below its streaming rate), the backward gained 10 %, the step did not move (19.65-19.76 against 19.74-19.86 ms).
+    static const bool no_stem_skip = TCVN_KNOB_SET("TCVN_NO_STEM_SKIP") || TCVN_KNOB_SET("TCVN_POOL0_BWD_FLAT");   // (the flat backward kernel reads every row)
     uint32_t* sact = nullptr;
     const void* cline = ws + L.zeros + 512;                 // the zero page is 1 KB; DMA sources use its first 256 B
     {
@@ -433,7 +435,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         ConvFwdArgs probe{};
         probe.mode = mode; probe.amode = A_STEM; probe.M = (int)M0; probe.N = cfg.init_ch; probe.K = 49 * cfg.in_ch; probe.Kp = e0.Kp; probe.C = cfg.in_ch;
         probe.H = Hc; probe.W = Wc; probe.Hin = cfg.H; probe.Win = cfg.W; probe.ldo = cfg.init_ch; probe.n_off = 0; probe.Out = ws + L.c0;
-        if (!no_stem_skip && L.sact >= 0 && stem_fwd_ok(probe) && (blocks[0].ld & 7) == 0 && coords != nullptr) {
+        if (!no_stem_skip && train && L.sact >= 0 && stem_fwd_ok(probe) && (blocks[0].ld & 7) == 0 && coords != nullptr) {
             sact = reinterpret_cast<uint32_t*>(ws + L.sact);
             if ((rc = stem_mark(coords, nnz, n, cfg.H, cfg.W, Hc, Wc, sact, data[s_b0], const_cast<void*>(cline), st))) return rc;
         }
@@ -445,7 +447,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         a.mode = mode; a.amode = A_STEM; a.A = ws + L.img; a.lda = cfg.in_ch; a.M = (int)M0; a.N = cfg.init_ch;
         a.K = 49 * cfg.in_ch; a.Kp = e.Kp; a.C = cfg.in_ch; a.H = Hc; a.W = Wc; a.Hin = cfg.H; a.Win = cfg.W;
         a.Wk = ws + L.wk + e.off; a.bias = data[s_b0]; a.Out = ws + L.c0; a.ldo = cfg.init_ch; a.n_off = 0;
-        a.part = train ? part : nullptr; a.nblk = conv_fwd_nblk(a); a.stem_act = sact;
+        a.part = train ? part : nullptr; a.nblk = conv_fwd_nblk(a);
         if ((rc = conv_fwd(a, st))) return rc;
         if ((rc = link(n0, part, a.nblk, cfg.init_ch, 0, cfg.init_ch, reinterpret_cast<double*>(ws + L.bstat0), M0))) return rc;
     }
@@ -453,7 +455,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         const BlockGeom& b0 = blocks[0];
         Tab t = tab(n0);
         Pool0Args a{mode, ws + L.c0, n, Hc, Wc, cfg.init_ch, t.sc, t.sh, data[s_a0], ws + L.D[0], b0.ld, b0.H, b0.W,
-                    train ? part : nullptr, pool0_grid(n, b0.H, b0.W), sact, cline};
+                    train ? part : nullptr, pool0_grid(n, b0.H, b0.W)};
         if ((rc = pool0_fwd(a, st))) return rc;
     }
     init_nblk = pool0_grid(n, blocks[0].H, blocks[0].W);

@@ -362,31 +362,7 @@ __global__ __launch_bounds__(256) void k_pool0_vec64(const Pool0Args a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; }
     const long npix = (long)a.n_img * a.Ho * a.Wo;
-    // Activity bitmap (StemActivity): a window position no hit reaches is not in HBM -- its row is `cline`.  The three window rows' bits of a
-    // pixel are fetched one pixel AHEAD (they decide the addresses of that pixel's nine loads: fetched in place they would add a dependent
-    // round trip per pixel).
-    const int WW = (a.Win + 31) >> 5;
-    const bf16* cl = reinterpret_cast<const bf16*>(a.cline) + c8 * 8;
-    auto win_bits = [&](long p, uint32_t (&b)[3]) {
-        b[0] = b[1] = b[2] = 7u;
-        if (a.act == nullptr || p >= npix) return;
-        const int wo = (int)(p % a.Wo);
-        const int ho = (int)((p / a.Wo) % a.Ho);
-        const long img = p / ((long)a.Wo * a.Ho);
-        const int x0 = 2 * wo, wi = x0 >> 5, sh = x0 & 31;
-        const uint32_t* r0 = a.act + (img * a.Hin + 2 * ho) * WW + wi;
-        const bool two = sh > 29 && wi + 1 < WW;                         // the three columns straddle two words
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const uint32_t lo = r0[dy * WW], hi = two ? r0[dy * WW + 1] : 0u;
-            b[dy] = (uint32_t)((((unsigned long long)hi << 32) | lo) >> sh) & 7u;
-        }
-    };
-    uint32_t bits[3], nbits[3];
-    long p = (long)blockIdx.x * 32 + (tid >> 3);
-    win_bits(p, bits);
-    for (; p < npix; p += (long)gridDim.x * 32) {
-        win_bits(p + (long)gridDim.x * 32, nbits);
+    for (long p = (long)blockIdx.x * 32 + (tid >> 3); p < npix; p += (long)gridDim.x * 32) {
         const int wo = (int)(p % a.Wo);
         const int ho = (int)((p / a.Wo) % a.Ho);
         const long img = p / ((long)a.Wo * a.Ho);
@@ -396,12 +372,10 @@ __global__ __launch_bounds__(256) void k_pool0_vec64(const Pool0Args a) {
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const bf16* src = ((bits[dy] >> dx) & 1u) ? base + ((long)dy * a.Win + dx) * 64 : cl;
-                const u16x8 v = *reinterpret_cast<const u16x8*>(src);
+                const u16x8 v = *reinterpret_cast<const u16x8*>(base + ((long)dy * a.Win + dx) * 64);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += prelu(fmaf(bf2f(v[j]), sc[j], sh[j]), sl[j]);
             }
-        bits[0] = nbits[0]; bits[1] = nbits[1]; bits[2] = nbits[2];
         u16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

@@ -594,10 +594,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_fwd2_bf16(const ConvFwdArgs g, 
         for (int k = 0; k < 4; ++k) {
             const int idx = tid + 256 * k, p = idx >> 3, c8 = idx & 7;
             const int py = p >> 4, px = p & 15;
-            bool st_ok = (oy0 + py < Ho) & (ox0 + px < Wo);
-            if (st_ok && g.stem_act != nullptr)                              // rows of positions no hit reaches are not stored (they hold bf16(bias): cline)
-                st_ok = (g.stem_act[(n * Ho + oy0 + py) * (long)((Wo + 31) >> 5) + ((ox0 + px) >> 5)] >> ((ox0 + px) & 31)) & 1u;
-            if (st_ok)
+            if ((oy0 + py < Ho) & (ox0 + px < Wo))
                 *reinterpret_cast<u16x8*>(Out + ((n * Ho + oy0 + py) * (long)Wo + ox0 + px) * g.ldo + c8 * 8) =
                     *reinterpret_cast<const u16x8*>(&ctile[p * ST_CP + c8 * 8]);
         }

@@ -30,7 +30,6 @@ struct ConvFwdArgs {
     double* part; int nblk;          // [nblk][N][2]; nblk = grid.x
     float drop_p; uint64_t seed; uint32_t stream_id;
     uint32_t* keep_out;              // optional [M]: the 3x3 pair kernel stores the keep flags of a pixel's N <= 32 channels as one word
-    const uint32_t* stem_act;        // optional (bf16 conv0 kernel): activity bitmap of the output map (StemActivity); rows of positions no hit reaches are NOT stored
     int act_fused;                   // bf16 3x3 tile kernels (forward pair kernel, weight gradient): Aact is the RAW [pixels][128] map; the wave that
                                      // fetched a row applies prelu(sc*x + sh, sl) to it in LDS, once, before any tap reads it -- no activated copy in HBM
 };
@@ -81,7 +80,6 @@ int scatter_pixels(const ScatterArgs& a, hipStream_t st);
 struct Pool0Args {
     int mode; const void* X; int n_img, Hin, Win, C; const float *sc, *sh, *sl;
     void* Out; long ldo; int Ho, Wo; double* part; int nblk;
-    const uint32_t* act; const void* cline;      // optional (bf16, C == 64): StemActivity bitmap of X and the row every inactive position holds
 };
 int pool0_fwd(const Pool0Args& a, hipStream_t st);
 int pool0_grid(int n_img, int Ho, int Wo);
@@ -294,8 +292,9 @@ int act_pool_f32(const ActPoolArgs& a, hipStream_t st);      // fp32 operands; C
 
 // bf16 stem kernels (stem.hip)
 // Activity of the conv0 output map: bit (img, oy, ox) is set when at least one hit of the COO list lies in the 7x7 / stride-2 window of output
-// position (oy, ox).  Every other position holds exactly bf16(bias) (a sum of zeros plus the bias) -- the dense stem kernels neither store nor
-// load those rows (conv0 output, its gradient): they read one shared 128-B row `cline` instead.  Words per map row: stem_act_words(Wc).
+// position (oy, ox).  Every other position holds exactly bf16(bias) (a sum of zeros plus the bias): the pooling backward kernel reads one
+// shared 128-B row `cline` for them and does not store their gradient rows (nothing reads those: the conv0 weight gradient walks the hit
+// list).  Words per map row: stem_act_words(Wc).
 inline int stem_act_words(int Wc) { return (Wc + 31) >> 5; }
 int stem_mark(const int* coords, long nnz, int n_img, int H, int W, int Hc, int Wc, uint32_t* act, const float* bias, void* cline, hipStream_t st);
 int pool0_bwd_vec_grid(int n_img, int Hin, int Win);

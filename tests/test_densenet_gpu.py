@@ -329,8 +329,7 @@ eng.forward(batch[5].cuda(), batch[6].cuda(), n_img, out, train=True, seed=1)
 torch.cuda.synchronize()
 result = dict(c0=eng.tap('conv0').clone().cpu(), d1=eng.tap('dense1').float().cpu(), out=out.cpu())
 """, dict(TCVN_STEM_FWD_V1="1"))
-    # round 4: the product stores only the conv0 rows some hit reaches (stem activity bitmap); every other row is exactly bf16(bias),
-    # which the first kernel (it stores everything) shows
+    # round 4: what the stem activity bitmap relies on -- every conv0 row that no hit reaches is exactly bf16(bias)
     act = _conv0_activity(batch[5], n_img, c0.shape[1], c0.shape[2])
     a16, r16 = c0.view(torch.int16), ref["c0"].view(torch.int16)
     assert torch.equal(a16[act], r16[act])
@@ -609,10 +608,10 @@ result = dict(out=out, taps=taps, grads=grads, y=y, xa_absmax=xa.abs().max().ite
 
 
 def test_stem_activity_bitmap_is_bit_identical_to_the_dense_stem():
-    """Round 4: the dense stem kernels (conv0, pooling forward / backward) skip the conv0-output rows -- and their gradient rows -- that no hit
-    reaches and read one shared bf16(bias) row instead (stem_mark's bitmap) against the same kernels touching every row (TCVN_NO_STEM_SKIP on
-    the validation build, separate process): the values every kernel sees are the same, so embedding, taps and gradients are bit-identical
-    (gradients up to the run-to-run noise of the kernels that use atomics)."""
+    """Round 4: the stem's pooling backward kernel reads one shared bf16(bias) row for the conv0-output positions no hit reaches and does not
+    store their gradient rows (stem_mark's bitmap) against the same kernel touching every row (TCVN_NO_STEM_SKIP on the validation build,
+    separate process): the values every kernel sees are the same, so embedding, taps and gradients are bit-identical (gradients up to the
+    run-to-run noise of the kernels that use atomics)."""
     over = dict(densenet_structure=[2, 2], num_encoder_layers=2, dropout=0.1, pixel_noise_std=1e-3)
     cfg = O.tutorial_config(**over)
     batch = O.synthetic_batch([3, 1], 31, cfg)
