@@ -265,6 +265,7 @@ def main():
     ap.add_argument("--no-bwd-overlap", action="store_true", help="keep the weight-gradient kernels on the main stream (tcvn_backward_overlap(0): the library's default since round 4)")
     ap.add_argument("--bwd-overlap", action="store_true", help="A/B: 3x3 weight gradients on the plan's side stream (tcvn_backward_overlap(1), the default of rounds 2-3)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing (fp32_ms_per_step)")
+    ap.add_argument("--no-optimizer-leg", action="store_true", help="skip the with_optimizer_ms_per_step leg (5 extra steps): counter passes that are divided by the steps in the run")
     ap.add_argument("--dump-records", default="", help="write every profiled launch (name, ms, flops) to this JSON file")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # no launcher around us: start the ranks (no GPU call so far)
@@ -465,7 +466,7 @@ def main():
         if roof:
             out["roofline"] = roof
             out["kernels"] = kernels[:8]
-        if not args.ragged_inference and world == 1:
+        if not args.ragged_inference and world == 1 and not args.no_optimizer_leg:
             # beside the fwd+bwd figure BASELINE.json's metric names: the same step followed by the optimizer update the reference's
             # train.py performs (AdamW over two groups + gradient clipping; here one fused launch over the flat arenas)
             try:

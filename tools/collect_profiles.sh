@@ -19,8 +19,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/fp32 -o fp32 --output
 echo "[collect] sdxl kernel trace"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/sdxl -o sdxl --output-format csv -- python3 $ROOT/bench.py --sdxl --steps 2 --warmup 1 > $OUT/sdxl_bench_under_rocprof.json 2> $OUT/sdxl.err || exit 4
 echo "[collect] PMC passes (FETCH_SIZE, WRITE_SIZE separately)"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_f -o f --output-format csv -- python3 $ROOT/bench.py --precision bf16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fp32 --no-sdxl > /dev/null 2> $OUT/pmc_f.err || exit 5
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_w -o w --output-format csv -- python3 $ROOT/bench.py --precision bf16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fp32 --no-sdxl > /dev/null 2> $OUT/pmc_w.err || exit 6
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_f -o f --output-format csv -- python3 $ROOT/bench.py --precision bf16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fp32 --no-sdxl --no-optimizer-leg > /dev/null 2> $OUT/pmc_f.err || exit 5
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_w -o w --output-format csv -- python3 $ROOT/bench.py --precision bf16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fp32 --no-sdxl --no-optimizer-leg > /dev/null 2> $OUT/pmc_w.err || exit 6
 python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_f/f_counter_collection.csv $OUT/pmc_w/w_counter_collection.csv $OUT/pmc_traffic.json 2 > $OUT/pmc_traffic.log 2>&1
 echo "[collect] other configurations (un-profiled bench lines)"
 timeout -k 10 200 python3 $ROOT/bench.py --sdxl --steps 3 --warmup 1 > $OUT/sdxl_bench.json 2> /dev/null
