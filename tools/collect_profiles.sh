@@ -28,8 +28,8 @@ timeout -k 10 200 python3 $ROOT/bench.py --ragged-inference --no-cpu-baseline --
 timeout -k 10 200 python3 $ROOT/bench.py --batch 8 --no-cpu-baseline --no-fp32 --no-sdxl > $OUT/batch8_bench.json 2> /dev/null
 timeout -k 10 200 python3 $ROOT/bench.py --batch 64 --no-cpu-baseline --no-fp32 --steps 3 > $OUT/batch64_bench.json 2> /dev/null
 echo "[collect] sdxl PMC passes"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/spmc_f -o f --output-format csv -- python3 $ROOT/bench.py --sdxl --steps 1 --warmup 1 --no-profile > /dev/null 2> $OUT/spmc_f.err
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/spmc_w -o w --output-format csv -- python3 $ROOT/bench.py --sdxl --steps 1 --warmup 1 --no-profile > /dev/null 2> $OUT/spmc_w.err
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/spmc_f -o f --output-format csv -- python3 $ROOT/bench.py --sdxl --steps 1 --warmup 1 --no-profile --no-optimizer-leg > /dev/null 2> $OUT/spmc_f.err
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/spmc_w -o w --output-format csv -- python3 $ROOT/bench.py --sdxl --steps 1 --warmup 1 --no-profile --no-optimizer-leg > /dev/null 2> $OUT/spmc_w.err
 python3 $ROOT/tools/pmc_traffic.py $OUT/spmc_f/f_counter_collection.csv $OUT/spmc_w/w_counter_collection.csv $OUT/sdxl_pmc_traffic.json 2 > $OUT/sdxl_pmc_traffic.log 2>&1
 rm -rf $OUT/spmc_f $OUT/spmc_w
 rm -rf $OUT/*/*_kernel_trace.csv $OUT/pmc_f $OUT/pmc_w       # traces are large; the stats CSVs and the reduced JSON stay
