@@ -533,7 +533,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 a.mode = mode; a.amode = A_1X1; a.A = D; a.lda = bg.ld; a.M = (int)M; a.N = mid; a.K = ls.cin; a.Kp = e.Kp;
                 a.C = ls.cin; a.H = bg.H; a.W = bg.W; a.sc = t.sc; a.sh = t.sh; a.sl = data[ls.a1];
                 a.Wk = ws + L.wk + e.off; a.bias = data[ls.b1]; a.Out = ws + L.Y[bi][l]; a.ldo = mid; a.n_off = 0;
-                a.part = train ? part : nullptr; a.nblk = conv_fwd_grid((int)M);
+                a.part = train ? part : nullptr; a.nblk = conv_fwd_nblk(a);
                 if ((rc = conv_fwd(a, st))) return rc;
                 if ((rc = link(ls.n2, part, a.nblk, mid, 0, mid, reinterpret_cast<double*>(ws + L.bstatY[bi][l]), M))) return rc;
             }
@@ -607,7 +607,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 a.amode = A_1X1; a.A = ws + L.XP[bi]; a.lda = bg.ldp; a.K = bg.ldp; a.C = bg.ldp; a.sc = nullptr; a.sh = nullptr; a.sl = nullptr;
             }
             a.Wk = ws + L.wk + e.off; a.bias = data[bg.tb]; a.Out = ws + L.D[bi + 1]; a.ldo = nb.ld; a.n_off = 0;
-            a.part = train ? part : nullptr; a.nblk = conv_fwd_grid((int)Mn);
+            a.part = train ? part : nullptr; a.nblk = conv_fwd_nblk(a);
             if ((rc = conv_fwd(a, st))) return rc;
             init_nblk = a.nblk; init_ld = bg.Ctot / 2;
         } else {

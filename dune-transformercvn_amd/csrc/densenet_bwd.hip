@@ -193,7 +193,6 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
         float* P = reinterpret_cast<float*>(ws + L.pqD[bi]);
         float* Q = P + bg.ld;
         const double* bstatD = reinterpret_cast<const double*>(ws + L.bstatD[bi]);
-        const int nblkM = conv_fwd_grid((int)M);
 
         if (!bg.has_trans) {
             // final_norm + global average
@@ -248,7 +247,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             d.mode = mode; d.dmode = DG_1X1_POOL; d.e = e; d.M = (int)Mn; d.N = bg.Ctot; d.Kp = et.Kp;
             d.H = nb.H; d.W = nb.W; d.Hin = bg.H; d.Win = bg.W; d.Wt = ws + L.wk + et.off;
             d.Xin = D; d.ldxin = bg.ld; d.sc = sc_of(bg.tn); d.sh = sh_of(bg.tn); d.sl = data[bg.ta];
-            d.Gout = G; d.ldgo = bg.ld; d.accumulate = 1; d.part = part; d.nblk = conv_fwd_grid((int)Mn);
+            d.Gout = G; d.ldgo = bg.ld; d.accumulate = 1; d.part = part; d.nblk = conv_dgrad_nblk(d);
             if ((rc = conv_dgrad(d, st))) return rc;
             if ((rc = bwd_link(bg.tn, d.nblk, bstatD, M, P, Q, 1, bg.ta))) return rc;
         }
@@ -376,9 +375,9 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 ConvDgradArgs d{};
                 d.mode = mode; d.dmode = DG_1X1; d.e = e1; d.M = (int)M; d.N = ls.cin; d.Kp = et.Kp; d.H = bg.H; d.W = bg.W;
                 d.Wt = ws + L.wk + et.off; d.Xin = D; d.ldxin = bg.ld; d.sc = sc_of(ls.n1); d.sh = sh_of(ls.n1); d.sl = data[ls.a1];
-                d.Gout = G; d.ldgo = bg.ld; d.accumulate = 1; d.part = part; d.nblk = nblkM;
+                d.Gout = G; d.ldgo = bg.ld; d.accumulate = 1; d.part = part; d.nblk = conv_dgrad_nblk(d);
                 if ((rc = conv_dgrad(d, st))) return rc;
-                if ((rc = bwd_link(ls.n1, nblkM, bstatD, M, P, Q, 1, ls.a1))) return rc;
+                if ((rc = bwd_link(ls.n1, d.nblk, bstatD, M, P, Q, 1, ls.a1))) return rc;
             }
         }
     }

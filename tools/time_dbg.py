@@ -16,7 +16,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 batch_n = int(os.environ.get("TIME_BATCH", "32"))
 dev = torch.device("cuda", 0)
 opt = Options.load(os.path.join(ROOT, "dune-transformercvn_amd", "option_files", "tutorial_densenet_synthetic.json"))
-opt.batch_size, opt.num_gpu, opt.hip_precision, opt.seed = batch_n, 1, "bf16", 1234
+opt.batch_size, opt.num_gpu, opt.hip_precision, opt.seed = batch_n, 1, os.environ.get("TIME_PRECISION", "bf16"), 1234
 opt.training_file = "synthetic:64:8"
 torch.manual_seed(0)
 model = NeutrinoFullDenseTrainer(opt).to(dev)
