@@ -491,13 +491,17 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             // Train mode (round 4): the 1x1 runs on the RAW concat buffer, norm1 + PReLU1 applied to the landed LDS tiles (fwd1x1_fused.hip);
             // the fused 1x1 backward kernel rebuilds that activation from x, so the activated copy XA is neither written nor read.
             static const bool no_fuse1 = TCVN_KNOB_SET("TCVN_NO_FWD1_FUSE") || TCVN_KNOB_SET("TCVN_NO_BWD1_FUSE");
-            if (train && fast1 && !no_fuse1 && mid == 128 && mode == MODE_BF16) {
+            if ((train || fuse_ya) && fast1 && !no_fuse1 && mid == 128 && mode == MODE_BF16) {
                 const WkEntry& e = wk_find(ls.w1, 0, 1);
                 Tab t1 = tab(ls.n1);
                 Fwd1x1Args fa{};
                 fa.Xin = D; fa.ldx = bg.ld; fa.cin = ls.cin; fa.sc = t1.sc; fa.sh = t1.sh; fa.sl = data[ls.a1]; fa.M = M;
                 fa.Wfrag = ws + L.wk + e.off; fa.Kp = e.Kp; fa.bias = data[ls.b1]; fa.Out = ws + L.Y[bi][l]; fa.zeros = ws + L.zeros;
-                fa.part = part; fa.nblk = fwd1x1_fused_nblk(fa);
+                fa.part = train ? part : nullptr; fa.nblk = fwd1x1_fused_nblk(fa);
+                if (!train) {                  // eval: norm2 + PReLU2 in the epilogue, the activated map is the only output (as k_gemm_nt_bf16<.., XF = 2>)
+                    Tab t2 = tab(ls.n2);
+                    fa.osc = t2.sc; fa.osh = t2.sh; fa.osl = data[ls.a2]; fa.Out = ws + L.YA[bi][l];
+                }
                 if (fwd1x1_fused_ok(fa)) {
                     if ((rc = fwd1x1_fused(fa, st))) return rc;
                     if ((rc = link(ls.n2, part, fa.nblk, mid, 0, mid, reinterpret_cast<double*>(ws + L.bstatY[bi][l]), M))) return rc;

@@ -24,7 +24,9 @@ template <int NKC> struct FwdCfg {
     static constexpr int SMEM = OFF_TAB + 3 * NKC * 128 * 4;       // NKC = 1: 35 328 B, NKC = 2: 53 248 B (three workgroups per CU)
 };
 
-template <int NKC>
+// OACT (eval mode: running statistics, so no batch reduction separates the 1x1 output from its BatchNorm): the epilogue applies norm2 + PReLU2
+// to the fp32 result before the one rounding -- Out is the activated map the 3x3 kernel stages, the raw bottleneck map does not exist.
+template <int NKC, bool OACT>
 __global__ __launch_bounds__(256, 3) void k_fwd1x1_fused_bf16(const Fwd1x1Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef FwdCfg<NKC> C;
@@ -56,7 +58,9 @@ __global__ __launch_bounds__(256, 3) void k_fwd1x1_fused_bf16(const Fwd1x1Args g
         const bool ok = i < K;
         tab[i] = ok ? g.sc[i] : 0.f; tab[NKC * 128 + i] = ok ? g.sh[i] : 0.f; tab[2 * NKC * 128 + i] = ok ? g.sl[i] : 0.f;
     }
-    const float cbias = g.bias[(tid >> 6) * 32 + (tid & 31)];              // this lane's output column in MFMA layout: wave*32 + (lane & 31)
+    const int ocol = (tid >> 6) * 32 + (tid & 31);                         // this lane's output column in MFMA layout: wave*32 + (lane & 31)
+    const float cbias = g.bias[ocol];
+    const float o_sc = OACT ? g.osc[ocol] : 1.f, o_sh = OACT ? g.osh[ocol] : 0.f, o_sl = OACT ? g.osl[ocol] : 1.f;
     float st1[8], st2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
@@ -170,7 +174,11 @@ __global__ __launch_bounds__(256, 3) void k_fwd1x1_fused_bf16(const Fwd1x1Args g
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) cw[(i * 32 + (e & 3) + 8 * (e >> 2)) * CLD] = f2bf(acc[i][e] + cbias);
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[i][e] + cbias;
+                    if (OACT) v = prelu(fmaf(v, o_sc, o_sh), o_sl);
+                    cw[(i * 32 + (e & 3) + 8 * (e >> 2)) * CLD] = f2bf(v);
+                }
         }
         __syncthreads();
         // ---- epilogue: statistics of the rounded values, 16-B stores (a tile of Y is 16 KB contiguous)
@@ -220,6 +228,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd1x1_fused_bf16(const Fwd1x1Args g
 
 bool fwd1x1_fused_ok(const Fwd1x1Args& a) {
     if (!a.Xin || !a.Out || !a.Wfrag || !a.zeros || !a.bias || !a.sc || !a.sh || !a.sl) return false;
+    if (a.osc != nullptr && (a.part != nullptr || !a.osh || !a.osl)) return false;      // the output activation is the eval-mode epilogue: no statistics
     if (a.cin <= 0 || a.cin > 256 || a.Kp < a.cin || a.Kp > 256 || (a.Kp & 15) || (a.ldx & 7) || a.ldx < a.cin) return false;
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.Xin) | reinterpret_cast<uintptr_t>(a.Out) | reinterpret_cast<uintptr_t>(a.Wfrag);
     return (al & 15) == 0;
@@ -237,15 +246,19 @@ int fwd1x1_fused(const Fwd1x1Args& a, hipStream_t st) {
     if (a.part != nullptr && a.nblk != fwd1x1_fused_nblk(a)) { fprintf(stderr, "tcvn: fwd1x1_fused nblk mismatch\n"); return -3; }
     static bool attr = false;
     if (!attr) {
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd1x1_fused_bf16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd1x1_fused_bf16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const void* fns[4] = {reinterpret_cast<const void*>(k_fwd1x1_fused_bf16<1, false>), reinterpret_cast<const void*>(k_fwd1x1_fused_bf16<2, false>),
+                              reinterpret_cast<const void*>(k_fwd1x1_fused_bf16<1, true>), reinterpret_cast<const void*>(k_fwd1x1_fused_bf16<2, true>)};
+        for (const void* f : fns) TCVN_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     // SURVEY 8(d) strict bytes: x read once, Y written once
     ProfScope ps("k_fwd1x1_fused_bf16", 2.0 * a.M * 128.0 * a.cin, (double)a.M * 2.0 * (a.cin + 128.0), st);
     const int nblk = fwd1x1_fused_nblk(a);
-    if (a.Kp <= 128) hipLaunchKernelGGL(k_fwd1x1_fused_bf16<1>, dim3(nblk), dim3(256), FwdCfg<1>::SMEM, st, a);
-    else hipLaunchKernelGGL(k_fwd1x1_fused_bf16<2>, dim3(nblk), dim3(256), FwdCfg<2>::SMEM, st, a);
+    const bool oact = a.osc != nullptr;
+    if (a.Kp <= 128 && oact) hipLaunchKernelGGL((k_fwd1x1_fused_bf16<1, true>), dim3(nblk), dim3(256), FwdCfg<1>::SMEM, st, a);
+    else if (a.Kp <= 128) hipLaunchKernelGGL((k_fwd1x1_fused_bf16<1, false>), dim3(nblk), dim3(256), FwdCfg<1>::SMEM, st, a);
+    else if (oact) hipLaunchKernelGGL((k_fwd1x1_fused_bf16<2, true>), dim3(nblk), dim3(256), FwdCfg<2>::SMEM, st, a);
+    else hipLaunchKernelGGL((k_fwd1x1_fused_bf16<2, false>), dim3(nblk), dim3(256), FwdCfg<2>::SMEM, st, a);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

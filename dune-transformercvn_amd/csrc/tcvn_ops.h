@@ -272,6 +272,7 @@ struct Fwd1x1Args {
     long M;
     const void* Wfrag; int Kp;              // W1 [128][Kp] in MFMA fragment order
     const float* bias; void* Out;           // Y [M][128] bf16
+    const float *osc, *osh, *osl;           // optional (eval mode, part == nullptr): Out = prelu(osc*(C + bias) + osh, osl) -- norm2 (running statistics) + PReLU2
     const void* zeros;
     double* part; int nblk;                 // [nblk][128][2] or null; nblk = fwd1x1_fused_nblk()
 };
