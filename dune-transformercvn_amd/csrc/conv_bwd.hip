@@ -41,6 +41,26 @@ __device__ __forceinline__ bool eff_vec(const EffSrc& e) {
            ((reinterpret_cast<uintptr_t>(e.G) & ALIGN) == 0) && ((reinterpret_cast<uintptr_t>(e.X) & ALIGN) == 0);
 }
 
+// four consecutive channels of a row (16 B of fp32, 8 B of bf16); the address is a multiple of that size
+template <typename T> __device__ __forceinline__ void load4(const T* p, float v[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <> __device__ __forceinline__ void load4<bf16>(const bf16* p, float v[4]) {
+    const u16x4 a = *reinterpret_cast<const u16x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = bf2f(a[j]);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float v[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float v[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float v[4]) {
+    u16x4 a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = f2bf(v[j]);
+    *reinterpret_cast<u16x4*>(p) = a;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // dgrad
 // ---------------------------------------------------------------------------------------------------------------------
@@ -53,6 +73,7 @@ __global__ __launch_bounds__(NT) void k_conv_dgrad(const ConvDgradArgs g) {
     __shared__ Tile<T, BM> As;
     __shared__ Tile<T, BN_> Bs;
     __shared__ double red[WM][BN_][3];
+    __shared__ float cx[DMODE == DG_1X1_POOL ? 4 : 1][DMODE == DG_1X1_POOL ? 32 * 33 : 1];      // pooled epilogue: wave-private 32 x 32 exchange patch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -133,10 +154,80 @@ __global__ __launch_bounds__(NT) void k_conv_dgrad(const ConvDgradArgs g) {
         }
 
         // epilogue: PReLU + BatchNorm backward of the consumer norm whose input is Xin
+        if (DMODE == DG_1X1_POOL && (g.N & 3) == 0) {
+            // Pooled rows (a transition's data gradient): every accumulator element feeds FOUR source pixels (x read, G read-add-write).  In MFMA
+            // layout that is 4-byte accesses, 12 per element -- the fp32 parity mode spent 6.7 ms per step here at a fifth of the HBM rate.  Each
+            // 32 x 32 accumulator tile crosses a wave-private LDS patch instead, so that a lane owns four consecutive channels of a row
+            // (16-B accesses of fp32) and all of a row's twelve accesses are requested before the first use.
+            float* cw = &cx[wave][0];
+            const int er = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN_ / WN) + j * 32 + c4;
+                float sc[4], sh[4], sl[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const bool ok = n + k < g.N; sc[k] = ok ? g.sc[n + k] : 0.f; sh[k] = ok ? g.sh[n + k] : 0.f; sl[k] = ok ? g.sl[n + k] : 0.f; }
+                float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f}, t3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) cw[((q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[i][j][q];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the patch is this wave's own: LDS operations of a wave complete in order
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int row = ps * 8 + er;
+                        const int m = m0 + wm * (BM / WM) + i * 32 + row;
+                        float cv[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) cv[k] = cw[row * 33 + c4 + k];
+                        if (m < g.M && n < g.N) {
+                            const int hw = g.H * g.W;
+                            const int img = m / hw, rem = m - img * hw;
+                            const int ho = rem / g.W, wo = rem - ho * g.W;
+                            const long p00 = ((long)img * g.Hin + 2 * ho) * g.Win + 2 * wo;
+                            float xv[4][4], gv[4][4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const long px = p00 + (t >> 1) * g.Win + (t & 1);
+                                load4<T>(Xin + px * g.ldxin + n, xv[t]);
+                                if (g.accumulate) load4<T>(Gout + px * g.ldgo + n, gv[t]);
+                                else { gv[t][0] = 0.f; gv[t][1] = 0.f; gv[t][2] = 0.f; gv[t][3] = 0.f; }
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const long px = p00 + (t >> 1) * g.Win + (t & 1);
+                                float o[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const float x = xv[t][k];
+                                    const float u = fmaf(x, sc[k], sh[k]);
+                                    const float dA = 0.25f * cv[k];
+                                    const float du = u > 0.f ? dA : sl[k] * dA;
+                                    t1[k] += du; t2[k] = fmaf(du, x, t2[k]); t3[k] += u > 0.f ? 0.f : dA * u;
+                                    o[k] = gv[t][k] + sc[k] * du;
+                                }
+                                store4<T>(Gout + px * g.ldgo + n, o);
+                            }
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // all reads of the patch are done before the next tile overwrites it
+                }
+                // this lane's four channels -> the sums of column (lane & 31) of sub-tile j, as the reduction below expects them:
+                // fold the 8 row lanes (lane bits 3..5), then lane l takes channel l & 3 of the group l >> 2
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double a = (double)t1[k], b = (double)t2[k], c = (double)t3[k];
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+                    // lanes 0..7 hold the totals of channels 4*lane + k: route them to lane 4*(lane & 7) + k
+                    const double ra = __shfl(a, (lane & 31) >> 2), rb = __shfl(b, (lane & 31) >> 2), rc = __shfl(c, (lane & 31) >> 2);
+                    if (((lane & 31) & 3) == k && lane < 32) { s1[j] += ra; s2[j] += rb; s3[j] += rc; }
+                }
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN_ / WN) + j * 32 + (lane & 31);
-            if (n >= g.N) continue;
+            const int n = n0 + wn * (BN_ / WN) + j * 32 + (lane & 31);            if (n >= g.N) continue;
             const float sc = g.sc[n], sh = g.sh[n], sl = g.sl[n];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
