@@ -491,7 +491,8 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             // Train mode (round 4): the 1x1 runs on the RAW concat buffer, norm1 + PReLU1 applied to the landed LDS tiles (fwd1x1_fused.hip);
             // the fused 1x1 backward kernel rebuilds that activation from x, so the activated copy XA is neither written nor read.
             static const bool no_fuse1 = TCVN_KNOB_SET("TCVN_NO_FWD1_FUSE") || TCVN_KNOB_SET("TCVN_NO_BWD1_FUSE");
-            if ((train || fuse_ya) && fast1 && !no_fuse1 && mid == 128 && mode == MODE_BF16) {
+            static const bool no_wide1 = TCVN_KNOB_SET("TCVN_NO_FWD1_WIDE");         // validation build: wide layers on k_act_bf16 + the 128-row GEMM
+            if ((train || fuse_ya) && fast1 && !no_fuse1 && mid == 128 && mode == MODE_BF16 && !(no_wide1 && wk_find(ls.w1, 0, 1).Kp > 256)) {
                 const WkEntry& e = wk_find(ls.w1, 0, 1);
                 Tab t1 = tab(ls.n1);
                 Fwd1x1Args fa{};
