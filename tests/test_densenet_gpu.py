@@ -639,3 +639,57 @@ result = dict(out=out, taps=taps, grads=grads)
     same = [k for k in grads if torch.equal(grads[k], ref["grads"][k])]
     print("stem activity bitmap vs dense stem: bit-identical gradients", len(same), "of", len(grads), "; largest differences", errs[:4])
     assert errs[0][0] < GRAD_TOL and len(same) >= 0.75 * len(grads), errs[:8]
+
+
+@pytest.mark.parametrize("init_ch,structure,hw", [(200, [4], (104, 72)),      # cin 200..296: two and three column slices, resident and streamed forward chunks
+                                                  (100, [3], (104, 72)),      # cin 100, 132, 164: a last partial 8-channel chunk (cin % 8 == 4)
+                                                  (250, [10], (56, 40))])     # cin 250..538 (cin % 8 == 2): up to four slices, K extents 256..544 (> 512: the forward falls back, backward five slices)
+def test_fused_1x1_kernels_on_odd_widths_and_partial_tiles(init_ch, structure, hw):
+    """The fused 1x1 forward / backward kernels against the kernels they replace (TCVN_NO_BWD1_FUSE on the validation build disables both) on
+    layer widths and pixel counts the tutorial structure does not reach: channel counts that are not multiples of 8 (the last 16-B chunk of a row
+    carries foreign channels), 2-5 column slices, the streamed-chunk forward variant, and maps whose pixel count is not a multiple of the 64-row
+    tile (the launch's last, partial tile takes its own request path)."""
+    over = dict(densenet_structure=structure, initial_pixel_dim=init_ch, pixel_shape=hw, num_encoder_layers=2, dropout=0.0, pixel_noise_std=0.0)
+    cfg = O.tutorial_config(**over)
+    batch = O.synthetic_batch([2, 1], 37, cfg, event_hits=(60, 200), prong_hits=(20, 120))
+    sd = O.fill_state(cfg, 17)
+    n_img = int(batch[7].sum())
+    d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(10))
+    out, taps, grads = _run_bf16(cfg, sd, batch, True, d_out)
+    assert torch.isfinite(out).all() and all(torch.isfinite(g).all() for g in grads.values())
+    from variant_utils import run_on_debug_build
+    ref = run_on_debug_build(f"""
+import test_densenet_gpu as T
+from oracle import tcvn_oracle as O
+cfg = O.tutorial_config(**{over!r})
+batch = O.synthetic_batch([2, 1], 37, cfg, event_hits=(60, 200), prong_hits=(20, 120))
+sd = O.fill_state(cfg, 17)
+n_img = int(batch[7].sum())
+d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().manual_seed(10))
+out, taps, grads = T._run_bf16(cfg, sd, batch, True, d_out)
+result = dict(out=out, taps=taps, grads=grads)
+""", dict(TCVN_NO_BWD1_FUSE="1"))
+    e_out = rel_err(out, ref["out"])
+    e_tap = max(rel_err(taps[k], ref["taps"][k]) for k in taps)
+    is_bias = lambda k: k.endswith(("conv0.bias", "conv1.bias", "conv2.bias", "conv.bias"))      # exact-zero gradients: rounding noise only
+    errs = sorted(((((grads[k] - ref["grads"][k]).norm() / ref["grads"][k].norm().clamp_min(1e-30)).item(), k)
+                   for k in grads if ref["grads"][k].abs().max() > 0 and not is_bias(k)), reverse=True)
+    print(f"init {init_ch} {structure} {hw}: embedding {e_out:.2e}, taps {e_tap:.2e}, gradients", errs[:4])
+    assert e_out < 1e-2 and e_tap < 1e-2
+    # Gradients: the two paths sum the statistics in different orders, and through ten layers on 351 pixels single bf16 roundings of the
+    # forward move ill-conditioned gradients (norm0.weight: a sum of cancelling terms) by more than a fixed band allows.  The fp64 oracle
+    # arbitrates: every tensor of the fused path must point along the oracle's gradient at least as well as the three-kernel path does.
+    oref, _ = _oracle_grads(cfg, sd, batch, d_out)
+    worse = []
+    for k, r in oref.items():
+        if is_bias(k) or r.abs().max() < 1e-6:
+            continue
+        cos = lambda v: ((v.double().reshape(r.shape) * r).sum() / (v.double().norm() * r.norm()).clamp_min(1e-30)).item()
+        c_new, c_old = cos(grads[k]), cos(ref["grads"][k])
+        ratio = (grads[k].double().norm() / r.norm()).item()
+        if c_new < min(0.97, c_old - 0.03) or not (0.7 < ratio < 1.4):
+            worse.append((k, round(c_new, 4), round(c_old, 4), round(ratio, 3)))
+    print("tensors where the fused path tracks the fp64 oracle worse than the three-kernel path:", worse[:8])
+    assert not worse, worse[:8]
+    if len(structure) == 1 and structure[0] <= 4:
+        assert errs[0][0] < 3e-2, errs[:6]
