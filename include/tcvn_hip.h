@@ -243,9 +243,10 @@ int tcvn_dropout_keep(int kind, float p, uint64_t seed, uint32_t stream_id, int6
  * 2*M*N*K of that launch and bytes its algorithmic HBM traffic (operands once, results once).  Off by default; with a
  * filter set only the matching launches pay for their two events, which is cheap enough for the timed region.
  * --------------------------------------------------------------------------------------------------------------- */
-/* Backward runs the 3x3 / 1x1 weight-gradient kernels of the bf16 DenseNet on a plan-owned side stream beside the data-gradient
- * chain (double-buffered EY, event-released): -1.2 % step time on MI355X.  On by default; tcvn_backward_overlap(0) keeps everything
- * on the caller's stream (per-kernel timing: the overlapped kernels share the CUs and their launch times inflate). */
+/* tcvn_backward_overlap(1): backward runs the 3x3 weight-gradient kernels of the bf16 DenseNet (and the TN GEMMs of 1x1 layers the fused
+ * backward kernel does not serve) on a plan-owned side stream beside the data-gradient chain (double-buffered EY, event-released).
+ * OFF by default since round 4 (with the 1x1 backward fused into one kernel on the caller's stream the overlap no longer pays: same-box A/B
+ * 19.55 against 19.55-19.60 ms/step); on by default in rounds 2-3 (-1.2 % then). */
 void tcvn_backward_overlap(int on);
 void tcvn_profile_enable(int on);
 void tcvn_profile_filter(const char* label_substring); /* NULL or "" = every launch; else only matching kernel labels */
