@@ -13,6 +13,11 @@ __global__ __launch_bounds__(256) void k_bn_link(const BnLinkArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + wave;
     if (c >= a.C) return;
+    // the channel's parameters are requested FIRST, with the partial rows: read after the reduction they were a second, dependent round trip
+    // in a kernel that is nothing but latency (132 launches per step on each embedder's chain)
+    const float gamma = a.gamma[c], beta = a.beta[c];
+    const bool upd = a.train && a.running_mean != nullptr;
+    const float rmean = upd || !a.train ? a.running_mean[c] : 0.f, rvar = upd || !a.train ? a.running_var[c] : 0.f;
     double mean, var;
     if (a.train) {
         if (c >= a.c_new0 && c < a.c_new0 + a.n_new) {
@@ -39,17 +44,17 @@ __global__ __launch_bounds__(256) void k_bn_link(const BnLinkArgs a) {
             mean = a.bstat[c * 2]; var = a.bstat[c * 2 + 1];
         }
     } else {
-        mean = a.running_mean[c]; var = a.running_var[c];
+        mean = rmean; var = rvar;
     }
     if (lane == 0) {
         const float r = (float)(1.0 / sqrt(var + (double)a.eps));
-        const float sc = a.gamma[c] * r;
+        const float sc = gamma * r;
         a.sc[c] = sc;
-        a.sh[c] = a.beta[c] - (float)mean * sc;
-        if (a.train && a.running_mean != nullptr) {
+        a.sh[c] = beta - (float)mean * sc;
+        if (upd) {
             const double unb = a.count > 1 ? var * (double)a.count / (double)(a.count - 1) : var;
-            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
-            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+            a.running_mean[c] = (1.f - a.momentum) * rmean + a.momentum * (float)mean;
+            a.running_var[c] = (1.f - a.momentum) * rvar + a.momentum * (float)unb;
         }
     }
 }

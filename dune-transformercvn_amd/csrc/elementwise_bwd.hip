@@ -13,6 +13,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_link(const BnBwdLinkArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + wave;
     if (c >= a.C) return;
+    // everything the closing arithmetic needs is requested up front, with the partial rows (one round trip instead of two: see k_bn_link)
+    const double mu = a.bstat[c * 2], var = a.bstat[c * 2 + 1];
+    const float gam = a.gamma[c];
+    const float g_dg = a.dgamma[c], g_db = a.dbeta[c], g_ds = a.dslope[c];
+    const float p_old = a.accumulate_pq ? a.P[c] : 0.f, q_old = a.accumulate_pq ? a.Q[c] : 0.f;
     double s1 = 0, t2 = 0, s3 = 0;
     int b = lane;
     // Eight partial rows per trip = every row of a launch with <= 512 workgroups (all of them) in ONE round trip: 24 loads in flight
@@ -32,18 +37,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_link(const BnBwdLinkArgs a) {
     }
     s1 = wave_sum(s1); t2 = wave_sum(t2); s3 = wave_sum(s3);
     if (lane != 0) return;
-    const double mu = a.bstat[c * 2], var = a.bstat[c * 2 + 1];
     const double r = 1.0 / sqrt(var + (double)a.eps);
     const double dgamma = r * (t2 - mu * s1);
-    const double sc = (double)a.gamma[c] * r;
+    const double sc = (double)gam * r;
     const double M = (double)a.count;
-    a.dgamma[c] += (float)dgamma;
-    a.dbeta[c] += (float)s1;
-    a.dslope[c] += (float)s3;
+    a.dgamma[c] = g_dg + (float)dgamma;
+    a.dbeta[c] = g_db + (float)s1;
+    a.dslope[c] = g_ds + (float)s3;
     const float Px = (float)(-sc * dgamma * r / M);
     const float Qx = (float)(-sc * s1 / M + sc * dgamma * r * mu / M);
-    if (a.accumulate_pq) { a.P[c] += Px; a.Q[c] += Qx; }
-    else { a.P[c] = Px; a.Q[c] = Qx; }
+    a.P[c] = p_old + Px; a.Q[c] = q_old + Qx;
 }
 
 // global-average head backward: dz = dF/HW on every pixel, then PReLU+BN backward bookkeeping of final_norm
