@@ -5,8 +5,9 @@
 // input (k_act_bf16: 2*cin bytes written and read again per pixel and layer) does not exist for the layers this kernel serves; the fused
 // 1x1 backward kernel (bwd1x1_fused.hip) rebuilds the same activation from x on its side.
 // One workgroup = one 64-pixel tile, all 128 output channels (a wave owns 32 of them: its weight fragments for the whole K extent stay in
-// registers), two workgroups per CU for K <= 256 (dense blocks 1-2), one for K <= 512.  Arithmetic and summation orders are those of
-// k_gemm_nt_bf16<EPI_FWD> on the materialised operand: identical Y.
+// registers).  K <= 256 (dense blocks 1-2): one or two resident chunks, three to four workgroups per CU; 256 < K <= 512 (k_fwd1x1_wide_bf16):
+// the chunks stream through a two-slot ring, two workgroups per CU.  Arithmetic and summation orders are those of k_gemm_nt_bf16<EPI_FWD>
+// on the materialised operand: identical Y.  OACT (eval mode): norm2 + PReLU2 of the consumer in the epilogue.
 #include "tcvn_ops.h"
 #include "prof.h"
 
