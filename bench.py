@@ -344,7 +344,7 @@ def main():
     # Untimed survey step: every convolution-class launch bracketed by HIP events on its own stream, embedders serialised on
     # one stream so that the per-kernel times are not smeared by the overlap.  It names the dominant kernel.  Every rank runs
     # the same two extra steps (they contain collectives); only rank 0 records.
-    agg, kernels, top = {}, None, None
+    agg, kernels, top, biggest = {}, None, None, {}
     profiled = rank == 0 and not args.no_profile
     if not args.no_profile:
         rt.overlap_embedders = False
@@ -363,9 +363,12 @@ def main():
             if args.dump_records:
                 with open(args.dump_records, "w") as f:
                     json.dump(records, f)
+            biggest = {}                    # per label: the launch with the most algorithmic bytes (dense block 1 of the prong embedder)
             for name, ms, fl, by in records:
                 a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
                 a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
+                if by > biggest.get(name, (0.0, 0.0, 0.0))[0]:
+                    biggest[name] = (by, ms, fl)
             _lib.lib.tcvn_profile_reset()
             kernels = sorted(({"kernel": k, "launches": a[0], "ms": round(a[1], 3), "avg_ms": round(a[1] / a[0], 4),
                                "tflops": round(a[2] / a[1] / 1e9, 2) if a[1] > 0 else 0.0,
@@ -426,6 +429,12 @@ def main():
                 "measured": f"HIP events on the launch stream around all {sn} launches of one step, embedders serialised",
                 "bytes_definition": "SURVEY 8(d) strict: every operand read once, every result written once (the read of an "
                                     "accumulated-into gradient buffer is not counted)",
+                # the kernel's largest launch of the survey step (most algorithmic bytes: dense block 1 of the prong embedder), where launch
+                # overheads and the small maps of the deep blocks do not dilute the figure; `frac` above stays the all-launch average
+                "largest_launch": ({"bytes": biggest[top][0], "ms": round(biggest[top][1], 4),
+                                    "achieved": round(biggest[top][0] / biggest[top][1] / 1e6, 1), "unit": "GB/s",
+                                    "frac": round(biggest[top][0] / biggest[top][1] / 1e6 / HBM_PEAK_GBPS, 4)}
+                                   if hbm_bound and top in biggest and biggest[top][1] > 0 else None),
                 "overlapped_avg_launch_ms": round(ms / n, 4) if n else None,    # same kernel inside the timed (two-stream) region
                 "survey_ms_per_step": round(sum(a[1] for a in agg.values()), 2)}
     if world > 1:
