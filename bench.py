@@ -203,6 +203,33 @@ def fp32_parity_mode_ms(opt_path, args, dev, batch):
     return 1000 * (time.perf_counter() - t0) / 2
 
 
+def small_batch_ms(opt_path, args, dev, batch_n, steps=5):
+    """ms/step of the same bf16 fwd+loss+bwd step at `batch_n` events per GPU (8 = one rank's share of the north star's batch-64
+    strong-scaling case at 8 GPUs; 64 = that whole batch on one GPU): 2 warm-up + `steps` timed steps."""
+    from transformercvn.options import Options
+    from transformercvn.network.trainers.neutrino_full_dense_trainer import NeutrinoFullDenseTrainer
+    opt = Options.load(opt_path)
+    opt.batch_size, opt.num_gpu, opt.hip_precision, opt.seed = batch_n, 1, "bf16", 1234
+    opt.training_file = f"synthetic:64:{args.prongs}"
+    torch.manual_seed(0)
+    model = NeutrinoFullDenseTrainer(opt).to(dev)
+    model.train()
+    rt = model.network.hip_runtime()
+    batch = make_batch(batch_n, args.prongs, 1234, dev)
+
+    def step():
+        rt.zero_grad()
+        model.training_step(batch, 0).backward()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return 1000 * (time.perf_counter() - t0) / steps
+
+
 def sdxl_mode_ms(opt_path, args, dev):
     """ms/step of BASELINE config 4 (--sdxl embedder, batch 16 x 8 prongs, bf16; parity unpinned: diffusers is not available) so that the
     default run puts it on the driver's record: 1 warm-up + 2 timed steps."""
@@ -257,6 +284,7 @@ def main():
     ap.add_argument("--global-batch", type=int, default=None,
                     help="strong scaling: total events per step, split evenly over the ranks (north star: 64 at 8 GPUs)")
     ap.add_argument("--no-sdxl", action="store_true", help="skip the --sdxl (config 4) timing of the default run (sdxl_ms_per_step)")
+    ap.add_argument("--no-batch8", action="store_true", help="skip the small-batch timings of the default run (batch8_ms_per_step, batch64_ms_per_step)")
     ap.add_argument("--prongs", type=int, default=8)
     ap.add_argument("--dropout", type=float, default=None, help="override options.dropout (experiments only; the metric uses the file's 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -497,6 +525,21 @@ def main():
             torch.cuda.empty_cache()
             out["fp32_ms_per_step"] = round(fp32_parity_mode_ms(opt_path, args, dev, batch), 2)
             out["fp32_events_per_s"] = round(args.batch / out["fp32_ms_per_step"] * 1000, 1)
+        if (args.precision == "bf16" and world == 1 and not args.no_batch8 and not args.sdxl and not args.ragged_inference and not strong
+                and args.batch == 32):
+            # the strong-scaling regime of the north star (batch 64 over 8 GPUs = 8 events per rank) as this one GPU sees it: the per-rank
+            # share and the whole batch, so that the 8-way ceiling (batch-64 time / batch-8 time, before any exchange cost) is on the record
+            note("batch 8 and batch 64 per GPU (2 warm-up + 5 / 3 steps) ...")
+            model = rt = None
+            torch.cuda.empty_cache()
+            out["batch8_ms_per_step"] = round(small_batch_ms(opt_path, args, dev, 8), 3)
+            out["batch8_events_per_s"] = round(8 / out["batch8_ms_per_step"] * 1000, 1)
+            torch.cuda.empty_cache()
+            out["batch64_ms_per_step"] = round(small_batch_ms(opt_path, args, dev, 64, steps=3), 3)
+            out["strong_scaling_ceiling_8way"] = round(out["batch64_ms_per_step"] / out["batch8_ms_per_step"], 2)
+            out["batch8_note"] = ("same bf16 fwd+loss+bwd step at 8 events/GPU (one rank's share of batch 64 over 8 GPUs) and at 64 events on "
+                                  "this one GPU; ceiling = their ratio, no exchange cost in it")
+            torch.cuda.empty_cache()
         if args.precision == "bf16" and world == 1 and not args.no_sdxl and not args.sdxl and not args.ragged_inference and not strong:
             note("--sdxl embedder, config 4 (1 warm-up + 2 steps) ...")
             model = rt = None

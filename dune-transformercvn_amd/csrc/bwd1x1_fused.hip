@@ -12,7 +12,8 @@
 // the activated input exists in HBM for these kernels: per pixel and layer the backward of the 1x1 moves 512 + 6*cin bytes instead of
 // 1792 + 8*cin (EY written once and read twice, the activated copy read once, x and G as here).
 // The weight-gradient tile (128 x 128 fp32 = 64 accumulator registers per lane) stays in registers for the whole launch and leaves as one
-// slab per workgroup (k_slab_reduce, deterministic).
+// slab per workgroup (k_slab_reduce: the slabs of one y-slice are summed in a fixed order; launches with more than 32 slabs split them over
+// up to 16 y-slices whose partial sums meet in fp32 atomics, i.e. the last bits of a weight gradient can differ from run to run).
 #include "tcvn_ops.h"
 #include "prof.h"
 
@@ -40,7 +41,8 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* smem_base, int off_lo, i
     return __builtin_bit_cast(bf16x8_t, pr);
 }
 
-// [64 rows][128 columns] of a row-major bf16 matrix -> LDS, 16-B chunks XOR-swizzled by the row (slot s of row r holds source chunk s ^ (r & 15))
+// [64 rows][128 columns] of a row-major bf16 matrix -> LDS, 16-B chunks XOR-swizzled by the row (slot s of row r holds source chunk s ^ swz16(r):
+// conflict-free for the row-wise fragment reads of the data gradient AND for the transposed reads of the weight gradient, tcvn_common.h)
 __device__ __forceinline__ void dma64(char* smem_base, int buf_off, const bf16* __restrict__ A, long lda, int K, int k0, long m0, long M,
                                       const char* __restrict__ zeros, int wave, int lane) {
     const int rsub = lane >> 4, slot = lane & 15;
@@ -48,7 +50,7 @@ __device__ __forceinline__ void dma64(char* smem_base, int buf_off, const bf16* 
     for (int i = 0; i < ROWS / 16; ++i) {
         const int rg = wave + 4 * i;
         const int r = rg * 4 + rsub;
-        const int col = k0 + ((slot ^ (r & 15)) << 3);
+        const int col = k0 + ((slot ^ swz16(r)) << 3);
         const long m = m0 + r;
         const char* src = (m < M && col < K) ? reinterpret_cast<const char*>(A + m * lda + col) : zeros + (slot << 4);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -111,10 +113,11 @@ __global__ __launch_bounds__(256, 2) void k_bwd1x1_fused_bf16(const Bwd1x1Args g
     // the twelve DMAs and the four G loads -- per-lane 64-bit source pointers with their range selects are ~50 registers of loop
     // invariants next to the accumulators.  x chunks beyond cin are never requested: their LDS slots are zeroed once, nothing writes them.
     const int col_chunk = tid & 15;                                        // element-wise roles: 16 threads per row, 8 channels each
-    const bool col_ok = n0 + col_chunk * 8 < N;                            // a last, partial chunk (cin % 8 != 0) needs no masks: its tables and weight rows
-                                                                           // are zero beyond cin, so G is rewritten unchanged and the activated input is 0 there
+    const bool col_ok = n0 + col_chunk * 8 < N;
+    const int col_rem = N - (n0 + col_chunk * 8);                          // < 8 only in a last, partial chunk (cin % 8 != 0): the foreign channels beside it
+                                                                           // (the layer's own 3x3 output slice) are neither used as x nor rewritten in G
     const int d_r0 = (tid >> 6) * 4 + ((tid & 63) >> 4);                   // DMA: this lane's row in row group i is d_r0 + 16*i
-    const int d_chunk = (tid & 15) ^ (d_r0 & 15);
+    const int d_chunk = (tid & 15) ^ swz16(d_r0);
     const bool xchunk_ok = n0 + (d_chunk << 3) < N;
     const unsigned voffA = (unsigned)(d_r0 * 256 + (d_chunk << 4));
     const unsigned voffX = (unsigned)(d_r0 * (int)g.ldx * 2 + (d_chunk << 4));
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd1x1_fused_bf16(const Bwd1x1Args g
         int t_o = tid;
         asm volatile("" : "+v"(t_o));
         const int c8 = t_o & 15, c_r0 = t_o >> 4;                          // element-wise roles: rows c_r0 + 16*i, channel chunk c8
-        const int e_off = c_r0 * 256 + ((c8 ^ (c_r0 & 15)) << 4);          // (c_r0 + 16*i) & 15 == c_r0 & 15: the row group adds i*4096
+        const int e_off = c_r0 * 256 + ((c8 ^ swz16(c_r0)) << 4);          // (c_r0 + 16*i) & 15 == c_r0 & 15: the row group adds i*4096
         auto tab8 = [&](int which, float (&v)[8]) {
             const float4 a = *reinterpret_cast<const float4*>(tab + which * 128 + c8 * 8), b = *reinterpret_cast<const float4*>(tab + which * 128 + c8 * 8 + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(256, 2) void k_bwd1x1_fused_bf16(const Bwd1x1Args g
                 for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
             if (wave_live) {
                 // fragments one k-step ahead of the MFMAs that use them (left to the compiler all sixteen reads are hoisted: 64 registers);
-                // chunk (2*ks + h) ^ (r & 15) == (2*ks) ^ w with w = h ^ (r & 15)
-                const int a_base = OFF_E + r * 256, w4 = (h ^ (r & 15)) << 4;
+                // chunk (2*ks + h) ^ swz16(r) == (2*ks) ^ w with w = h ^ swz16(r)
+                const int a_base = OFF_E + r * 256, w4 = (h ^ swz16(r)) << 4;
                 auto afrag = [&](int ks, int i) {
                     return *reinterpret_cast<const bf16x8_t*>(smem + a_base + i * 8192 + (w4 ^ (ks << 5)));
                 };
@@ -248,7 +251,11 @@ __global__ __launch_bounds__(256, 2) void k_bwd1x1_fused_bf16(const Bwd1x1Args g
             for (int i = 0; i < ROWS / 16; ++i) {
                 if (m0 + c_r0 + 16 * i < g.M) {
                     const int xoff = OFF_X + e_off + i * 4096;
-                    const u16x8 xv = *reinterpret_cast<const u16x8*>(smem + xoff);
+                    u16x8 xv = *reinterpret_cast<const u16x8*>(smem + xoff);
+                    if (col_rem < 8) {                                      // partial chunk (never in the tutorial widths): foreign x -> 0, so no
+#pragma unroll                                                              // non-finite foreign value can reach the sums or the activated operand
+                        for (int j = 0; j < 8; ++j) xv[j] = j < col_rem ? xv[j] : (bf16)0;
+                    }
                     const float4 ca = *reinterpret_cast<const float4*>(crow + i * 16 * CLD);
                     const float4 cc = *reinterpret_cast<const float4*>(crow + i * 16 * CLD + 4);
                     const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cc.x, cc.y, cc.z, cc.w};
@@ -264,7 +271,13 @@ __global__ __launch_bounds__(256, 2) void k_bwd1x1_fused_bf16(const Bwd1x1Args g
                         o[j] = f2bf(bf2f(gv[j]) + csc[j] * du);
                         xa[j] = f2bf(prelu(u, csl[j]));
                     }
-                    *reinterpret_cast<u16x8*>(gbase + (long)i * 32 * g.ldg + voffG) = o;
+                    if (col_rem >= 8) *reinterpret_cast<u16x8*>(gbase + (long)i * 32 * g.ldg + voffG) = o;
+                    else {                                                  // partial chunk: the layer's own channels only (the next ones belong to its 3x3
+                        bf16* gp = reinterpret_cast<bf16*>(gbase + (long)i * 32 * g.ldg + voffG);     // output gradient, which other kernels may be reading)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (j < col_rem) gp[j] = o[j];
+                    }
                     *reinterpret_cast<u16x8*>(smem + xoff) = xa;
                 }
             }
@@ -282,8 +295,8 @@ __global__ __launch_bounds__(256, 2) void k_bwd1x1_fused_bf16(const Bwd1x1Args g
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int ac = wi * 8 + t * 4 + 2 * chalf + (tp >> 1), bc = wj * 8 + t * 4 + 2 * chalf + (tp >> 1);
-                a_lo[t] = OFF_E + rl * 256 + ((ac ^ rl) << 4) + sub; a_hi[t] = OFF_E + (rl + 4) * 256 + ((ac ^ (rl + 4)) << 4) + sub;
-                b_lo[t] = OFF_X + rl * 256 + ((bc ^ rl) << 4) + sub; b_hi[t] = OFF_X + (rl + 4) * 256 + ((bc ^ (rl + 4)) << 4) + sub;
+                a_lo[t] = OFF_E + rl * 256 + ((ac ^ swz16(rl)) << 4) + sub; a_hi[t] = OFF_E + (rl + 4) * 256 + ((ac ^ swz16(rl + 4)) << 4) + sub;
+                b_lo[t] = OFF_X + rl * 256 + ((bc ^ swz16(rl)) << 4) + sub; b_hi[t] = OFF_X + (rl + 4) * 256 + ((bc ^ swz16(rl + 4)) << 4) + sub;
             }
 #pragma unroll
             for (int ks = 0; ks < ROWS / 16; ++ks) {

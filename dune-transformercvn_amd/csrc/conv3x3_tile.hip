@@ -703,7 +703,10 @@ __device__ __forceinline__ void wg_kloop(f32x16 (&acc)[9], const char* smem, int
 // issue and 5 100 more until the slice loads queued behind it returned, i.e. the kernel moved its 2.1x redundant image traffic at
 // the HBM rate (3.2 TB/s) while the multiplying waves waited 9 600 of 13 700 cycles at the barrier.
 // Row space of a workgroup: row 0 = padded position t0 * TP - halo; ring slot = row & 511; table entry = row & 1023; the XOR
-// swizzle of a row's 16-B chunks uses row & 15 (TP and the ring are multiples of 16, so it equals the tile-relative row & 15).
+// swizzle of a row's 16-B chunks is swz16(row) (tcvn_common.h: a function of row & 15; TP and the ring are multiples of 16, so it
+// equals the tile-relative value).  Round 5: every LDS read of the multiplying waves is a transposed read of four consecutive rows x
+// 64 B; with the forward kernels' `row & 15` swizzle those four rows shared 16 banks (two- to four-way conflicts on all 160 reads
+// per wave and tile: the k loop was LDS-bound at ~5 300 cycles against 2 300 of MFMA issue).
 __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradArgs g, int n_img, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvFwdArgs& fa = g.fa;
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                 const int rg = w4 + 4 * i;
                 if (rg * 4 < n) {
                     const int row = row0 + rg * 4, rr = row + rsub;       // row0 multiple of 4: the group stays inside the ring
-                    const char* src = mrow[i] >= 0 ? reinterpret_cast<const char*>(YA + (long)mrow[i] * 128) + ((slot ^ (rr & 15)) << 4)
+                    const char* src = mrow[i] >= 0 ? reinterpret_cast<const char*>(YA + (long)mrow[i] * 128) + ((slot ^ swz16(rr)) << 4)
                                                    : zeros + (slot << 4);
                     // the DMA as inline assembly: behind the builtin the compiler orders every later LDS access of this wave (eff tile,
                     // table) behind vmcnt(0) -- it cannot know they touch other rows -- which would put the DMAs last in the iteration with
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                     const int row = row0 + (in ? rg * 4 : 0) + rsub;
                     mr[j] = tbl[row & (WG_TBL - 1)];
                     if (!in) mr[j] = -1;
-                    p[j] = smem + (row & (WG_RING - 1)) * 256 + ((cc ^ (row & 15)) << 4);
+                    p[j] = smem + (row & (WG_RING - 1)) * 256 + ((cc ^ swz16(row)) << 4);
                     v[j] = *reinterpret_cast<const u16x8*>(p[j]);
                 }
 #pragma unroll
@@ -913,7 +916,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                         const int row = row0 + (w4 + 4 * j) * 4 + rsub_x;
                         u16x8 o = act8_apply(rv[j], xtb);
                         if (rm[j] < 0) o = u16x8{0, 0, 0, 0, 0, 0, 0, 0};                  // padding position: a zero row
-                        *reinterpret_cast<u16x8*>(smem + (row & (WG_RING - 1)) * 256 + ((cc_x ^ (row & 15)) << 4)) = o;
+                        *reinterpret_cast<u16x8*>(smem + (row & (WG_RING - 1)) * 256 + ((cc_x ^ swz16(row)) << 4)) = o;
                     }
                     PAIR_PH(13);
                 }
@@ -970,8 +973,8 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int arow = q.halo + (tap / 3 - 1) * q.Wp + (tap % 3 - 1) + 8 * khalf + tq, r2 = arow + 4;
-            a_lo[tap] = arow * 256 + ((a_chunk ^ (arow & 15)) << 4) + a_sub;
-            a_hi[tap] = r2 * 256 + ((a_chunk ^ (r2 & 15)) << 4) + a_sub;
+            a_lo[tap] = arow * 256 + ((a_chunk ^ swz16(arow)) << 4) + a_sub;
+            a_hi[tap] = r2 * 256 + ((a_chunk ^ swz16(r2)) << 4) + a_sub;
         }
         const int b_off0 = (8 * khalf + tq) * 64 + b_colbyte;
         __syncthreads();                                                    // (1)

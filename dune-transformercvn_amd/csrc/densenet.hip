@@ -163,7 +163,8 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
         const bool tmat32 = bg.has_trans && cfg.mode == MODE_F32 && conv3x3_tile_enabled() && (bg.ld & 3) == 0;
         L.XP.push_back((tfast || tmat32) ? b.take((long)n * (bg.H / 2) * (bg.W / 2) * bg.ldp * esz) : -1);   // row stride bg.ldp, zero padded
         L.bstatD.push_back(b.take((long)bg.ld * 16));
-        max_part = std::max(max_part, 512L * std::max(mid, bg.Ctot) * 16);   // every conv launcher uses <= 512 workgroups
+        max_part = std::max(max_part, 512L * std::max(mid, bg.Ctot) * 16);   // the conv launchers use <= 512 workgroups ...
+        max_part = std::max(max_part, 768L * mid * 16);                      // ... but the fused 1x1 forward up to 768 (fwd1x1_fused_nblk: three per CU)
         maxY = std::max(maxY, M * mid);
     }
     L.bstat0 = b.take((long)cfg.init_ch * 16);
@@ -503,7 +504,9 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                     Tab t2 = tab(ls.n2);
                     fa.osc = t2.sc; fa.osh = t2.sh; fa.osl = data[ls.a2]; fa.Out = ws + L.YA[bi][l];
                 }
-                if (fwd1x1_fused_ok(fa)) {
+                // train mode: the activated copy XA is only dropped when the backward's fused 1x1 kernel will accept this layer (it rebuilds
+                // the activation from x); otherwise the step would die in backward after the forward has already run
+                if (fwd1x1_fused_ok(fa) && (!train || bwd1x1_fusable((int)bi, l, M, ws, L))) {
                     if ((rc = fwd1x1_fused(fa, st))) return rc;
                     if ((rc = link(ls.n2, part, fa.nblk, mid, 0, mid, reinterpret_cast<double*>(ws + L.bstatY[bi][l]), M))) return rc;
                     xa_skipped[bi][l] = 1;

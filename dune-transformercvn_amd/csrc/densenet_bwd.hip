@@ -69,6 +69,29 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     L.total = b.off;
 }
 
+bool DenseNetPlan::bwd1x1_fill(int bi, int l, long M, char* ws, const Layout& L, Bwd1x1Args& fa) const {
+    const BlockGeom& bg = blocks[bi];
+    const LayerSlots& ls = bg.layers[l];
+    const int mid = cfg.bn_size * cfg.growth;
+    if (L.XA[bi][l] < 0 || mid != 128 || L.slab1 < 0 || cfg.mode != MODE_BF16) return false;
+    float* tabs = reinterpret_cast<float*>(ws + L.tabs);
+    const WkEntry& etf = wk_find(ls.w1, 1, 1);
+    fa = Bwd1x1Args{};
+    fa.DU = ws + L.du; fa.Y = ws + L.Y[bi][l]; fa.PY = reinterpret_cast<float*>(ws + L.pqY); fa.QY = fa.PY + mid; fa.M = M;
+    fa.Xin = ws + L.D[bi]; fa.ldx = bg.ld; fa.cin = ls.cin;
+    fa.sc = tabs + tab_off(ls.n1); fa.sh = fa.sc + round_up(ls.n1.C, 8); fa.sl = data[ls.a1]; fa.Gout = ws + L.G[bi]; fa.ldg = bg.ld;
+    fa.Wfrag = ws + L.wk + etf.off; fa.Kp = etf.Kp; fa.zeros = ws + L.zeros; fa.part = reinterpret_cast<double*>(ws + L.bpart);
+    fa.slab = reinterpret_cast<float*>(ws + L.slab1); fa.slab_bytes = kSlabGemmBytes; fa.ldc = wk_find(ls.w1, 0).Kp;
+    fa.tail = reinterpret_cast<float*>(ws + L.slab1 + kSlabGemmBytes);
+    fa.nblk = bwd1x1_fused_nblk(fa);
+    return bwd1x1_fused_ok(fa);
+}
+bool DenseNetPlan::bwd1x1_fusable(int bi, int l, long M, char* ws, const Layout& L) const {
+    static const bool no_fuse1 = TCVN_KNOB_SET("TCVN_NO_BWD1_FUSE");
+    Bwd1x1Args fa;
+    return !no_fuse1 && bwd1x1_fill(bi, l, M, ws, L, fa);
+}
+
 // Blocks [bi_lo, bi_hi] of the backward pass (bi_hi == last block: also the output block; bi_lo == 0: also the stem).  A caller that
 // wants each block's parameter gradients as soon as they are final (data-parallel exchange overlapped with the rest of backward)
 // walks the blocks from the last to the first; one call with (n_blocks - 1, 0) is the whole backward.
@@ -283,16 +306,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             const bool xa_absent = bi < (int)xa_skipped.size() && l < (int)xa_skipped[bi].size() && xa_skipped[bi][l];
             Bwd1x1Args fa{};
             bool fuse1 = L.XA[bi][l] >= 0 && !no_fuse1 && mid == 128 && L.slab1 >= 0 && (ls.cin <= fuse1_maxcin || xa_absent);
-            if (fuse1) {
-                const WkEntry& etf = wk_find(ls.w1, 1, 1);
-                fa.DU = DU; fa.Y = Y; fa.PY = PY; fa.QY = QY; fa.M = M; fa.Xin = D; fa.ldx = bg.ld; fa.cin = ls.cin;
-                fa.sc = sc_of(ls.n1); fa.sh = sh_of(ls.n1); fa.sl = data[ls.a1]; fa.Gout = G; fa.ldg = bg.ld;
-                fa.Wfrag = ws + L.wk + etf.off; fa.Kp = etf.Kp; fa.zeros = ws + L.zeros; fa.part = part;
-                fa.slab = reinterpret_cast<float*>(ws + L.slab1); fa.slab_bytes = kSlabGemmBytes; fa.ldc = wk_find(ls.w1, 0).Kp;
-                fa.tail = reinterpret_cast<float*>(ws + L.slab1 + kSlabGemmBytes);
-                fa.nblk = bwd1x1_fused_nblk(fa);
-                fuse1 = bwd1x1_fused_ok(fa);
-            }
+            if (fuse1) fuse1 = bwd1x1_fill(bi, l, M, ws, L, fa);       // (the same function the forward asked before it dropped the activated copy)
             SlabJob w3jobs[2] = {};        // the 3x3 weight gradient's slab reductions, folded into the fused kernel's reduction launch (same stream only)
             bool w3_deferred = false;
             {   // conv2 (3x3) weight gradient: beside the rest of this layer's data-gradient chain

@@ -8,6 +8,7 @@
 
 namespace tcvn {
 
+struct Bwd1x1Args;
 struct Slot { std::string name; long numel; int kind; };
 struct BnSlots { int w = -1, b = -1, rm = -1, rv = -1, nbt = -1, C = 0, id = -1; };
 struct LayerSlots { BnSlots n1, n2; int a1, w1, b1, a2, w2, b2, cin; };
@@ -92,6 +93,10 @@ struct DenseNetPlan {
     int forward(int n, const int32_t* coords, const float* values, long nnz, int log_pixels, float noise_std, float* out,
                 long out_ld, char* ws, long ws_bytes, int train, uint64_t seed, hipStream_t st);
     int backward(int n, const float* d_out, long d_out_ld, char* ws, long ws_bytes, hipStream_t st, int bi_hi = -1, int bi_lo = 0);
+    // Arguments of the fused 1x1 backward kernel for block bi, layer l (PY / QY / part left to the caller) -- the ONE place that decides whether a
+    // layer's backward can take it: the forward asks before it drops the activated copy XA, the backward fills its launch from the same function
+    bool bwd1x1_fill(int bi, int l, long M, char* ws, const Layout& L, Bwd1x1Args& fa) const;
+    bool bwd1x1_fusable(int bi, int l, long M, char* ws, const Layout& L) const;
     std::vector<int> unpack_first;   // first unpack descriptor of every block (+ total): partial backward calls unpack their own blocks
     int tap(int n, const char* name, long* off, int* tn, int* th, int* tw, int* tc, int* tld, int* tes) const;
 };

@@ -31,7 +31,7 @@ __device__ __forceinline__ void dma_tile(char* smem_base, int buf_off, const bf1
     for (int i = 0; i < ROWS / 16; ++i) {
         const int rg = wave + 4 * i;
         const int r = rg * 4 + rsub;
-        const int col = col0 + ((slot ^ (r & 15)) << 3);
+        const int col = col0 + ((slot ^ swz16(r)) << 3);
         const long m = m0 + r;
         const char* src = (m < m_end && col < ncols) ? reinterpret_cast<const char*>(X + m * ld + col) : zeros + (slot << 4);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const GemmTnArgs g, lon
 #pragma unroll
         for (int it = 0; it < ROWS * 16 / 256; ++it) {
             const int idx = tid + 256 * it, row = idx >> 4, slot = idx & 15;
-            const int cl = (slot ^ (row & 15)) << 3;                       // column inside the 128-column tile
+            const int cl = (slot ^ swz16(row)) << 3;                       // column inside the 128-column tile
             if (m0 + row < m_end && j0 + cl < g.Rreal) {
                 u16x8* p = reinterpret_cast<u16x8*>(smem + buf + row * 256 + (slot << 4));
                 const u16x8 v = *p;
@@ -118,10 +118,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(const GemmTnArgs g, lon
             bf16x8_t a[2], b[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                a[t] = tr_frag(smem, lb + row * 256 + ((achunk[t] ^ (row & 15)) << 4) + sub,
-                               lb + row2 * 256 + ((achunk[t] ^ (row2 & 15)) << 4) + sub);
-                b[t] = tr_frag(smem, rb + row * 256 + ((bchunk[t] ^ (row & 15)) << 4) + sub,
-                               rb + row2 * 256 + ((bchunk[t] ^ (row2 & 15)) << 4) + sub);
+                a[t] = tr_frag(smem, lb + row * 256 + ((achunk[t] ^ swz16(row)) << 4) + sub,
+                               lb + row2 * 256 + ((achunk[t] ^ swz16(row2)) << 4) + sub);
+                b[t] = tr_frag(smem, rb + row * 256 + ((bchunk[t] ^ swz16(row)) << 4) + sub,
+                               rb + row2 * 256 + ((bchunk[t] ^ swz16(row2)) << 4) + sub);
             }
 #pragma unroll
             for (int ta = 0; ta < 2; ++ta)

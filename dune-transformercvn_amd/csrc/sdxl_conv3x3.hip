@@ -633,7 +633,10 @@ __device__ __forceinline__ bf16x8_t tr_frag_(const char* smem_base, int off_lo, 
     struct { s16x4_ a, b; } pr = {lo, hi};
     return __builtin_bit_cast(bf16x8_t, pr);
 }
-__device__ __forceinline__ int swz(int pix, int chunk, int sub) { return pix * 128 + ((chunk ^ (pix & 7)) << 4) + sub; }
+// 128-B pixel rows: two rows per 256 B of banks.  A transposed read (half a wave) takes four consecutive pixels x one 64-B half row; with
+// `chunk ^ (pix & 7)` pixels p and p + 2 of such a group landed on the same 16 banks (same row parity, same half) -- bit 1 of the pixel index
+// now selects the half, so the four pixels of a group cover four different 64-B bank ranges whatever their alignment.
+__device__ __forceinline__ int swz(int pix, int chunk, int sub) { return pix * 128 + ((chunk ^ ((((pix >> 1) & 1) << 2) | (pix & 3))) << 4) + sub; }
 
 constexpr int WG_PATCH = PH * PW * 128;               // 43 520
 constexpr int WG_DOUT = TH * TW * 128;                // 32 768

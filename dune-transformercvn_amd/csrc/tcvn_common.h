@@ -47,6 +47,13 @@ template <typename T> __device__ __forceinline__ float round_to(float v) { retur
 
 __device__ __forceinline__ float prelu(float u, float a) { return u > 0.f ? u : a * u; }
 
+// XOR swizzle of the sixteen 16-B chunks of a 256-B LDS row that is read BOTH ways: slot = chunk ^ swz16(row).  Row-wise b128 fragment reads
+// (16 consecutive rows, one chunk) need a bijection of row & 15 onto the slots; the transposed reads (ds_read_b64_tr_b16: half a wave = four
+// consecutive rows x one aligned 64-B quad of chunks) need the QUAD index (slot >> 2) to differ between four consecutive rows, whatever
+// their alignment -- with the plain `row & 15` the quad moves with (row >> 2), so the four rows of a transpose group fall on the same 16 banks
+// (rocprofv3 round 4: LDS_BANK_CONFLICT = 2.6 x the LDS-active cycles of the 3x3 weight-gradient kernel).  Here row & 3 picks the quad.
+__device__ __forceinline__ int swz16(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
 // load 8 consecutive elements as float (vector path requires 16B/32B alignment)
 template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
 template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {

@@ -249,7 +249,7 @@ struct Bwd1x1Args {
     const void* DU; const void* Y;          // [M][128] bf16 each: the EffSrc (G, X) of the bottleneck output
     const float *PY, *QY;                   // [128]
     long M;
-    const void* Xin; long ldx; int cin;     // raw concat buffer (norm1 input), its row pitch, channels of this layer (cin % 8 == 0)
+    const void* Xin; long ldx; int cin;     // raw concat buffer (norm1 input), its row pitch, channels of this layer (any count: a partial last 8-channel chunk is masked)
     const float *sc, *sh, *sl;              // norm1 (scale, shift) table, PReLU1 slope
     void* Gout; long ldg;                   // gradient accumulator of the concat buffer (read-add-write on [0, cin))
     const void* Wfrag; int Kp;              // W1 transposed ([cin][128]) in MFMA fragment order; Kp == 128

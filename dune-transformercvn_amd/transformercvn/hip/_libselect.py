@@ -12,6 +12,8 @@ def use(name: str) -> None:
     global NAME
     if _bound:
         raise RuntimeError("transformercvn.hip._lib is already bound to " + NAME)
-    if name not in ("libtcvn_hip.so", "libtcvn_hip_dbg.so"):
+    # product library, the validation build, or a kept copy of an earlier validation build (libtcvn_hip_dbg_<tag>.so: same-box A/B timing,
+    # tools/time_dbg.py TIME_LIB=...)
+    if name != "libtcvn_hip.so" and not (name.startswith("libtcvn_hip_dbg") and name.endswith(".so") and "/" not in name):
         raise ValueError(name)
     NAME = name

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/perblock
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT/t -o t --output-format csv -- python3 $ROOT/bench.py --precision bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-sdxl --no-profile --no-bwd-overlap "$@" > $OUT/bench.json 2> $OUT/err
+timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT/t -o t --output-format csv -- python3 $ROOT/bench.py --precision bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-sdxl --no-batch8 --no-profile --no-bwd-overlap "$@" > $OUT/bench.json 2> $OUT/err
 ls -la $OUT/t
 python3 - <<PY
 import csv,glob

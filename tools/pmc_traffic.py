@@ -14,7 +14,7 @@ import sys
 
 LABELS = {            # bench.py label -> substring of the demangled kernel name
     "k_bwd1x1_fused_bf16": "k_bwd1x1_fused_bf16",
-    "k_fwd1x1_fused_bf16": "k_fwd1x1_fused_bf16",
+    "k_fwd1x1_fused_bf16": "k_fwd1x1_",            # both kernels behind the label: k_fwd1x1_fused_bf16<NKC> and k_fwd1x1_wide_bf16 (K > 256)
     "k_gemm_nt_bf16<dgrad1x1>": "k_gemm_nt_bf16<1, ",
     "k_gemm_nt_bf16<dgradtrans>": "k_gemm_nt_bf16<2, ",
     "k_conv3x3_dgrad_bf16": "k_conv3x3_dgrad",

@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-FLAGS="--precision bf16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fp32 --no-sdxl --no-bwd-overlap --no-optimizer-leg"
+FLAGS="--precision bf16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-fp32 --no-sdxl --no-batch8 --no-bwd-overlap --no-optimizer-leg"
 CMD="python3 bench.py $FLAGS"
 echo "[pmc] mfma pass"
 timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace -d $OUT/m -o m --output-format csv -- python3 $ROOT/bench.py $FLAGS > /dev/null 2> $OUT/m.err || { tail -5 $OUT/m.err; exit 1; }

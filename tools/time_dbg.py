@@ -5,7 +5,7 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dune-transformercvn_amd")]
 from transformercvn.hip import _libselect
-_libselect.use("libtcvn_hip_dbg.so")
+_libselect.use(os.environ.get("TIME_LIB", "libtcvn_hip_dbg.so"))      # TIME_LIB: e.g. a kept copy of an earlier validation build (same-box A/B)
 import torch
 import bench
 from transformercvn.options import Options

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r03c
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace -d $OUT/tr -o tr --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32 --no-sdxl --no-profile > $OUT/bench.json 2> $OUT/bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace -d $OUT/tr -o tr --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32 --no-sdxl --no-batch8 --no-profile > $OUT/bench.json 2> $OUT/bench.err
 ls $OUT/tr
 python3 - <<PY
 import csv, glob, collections
