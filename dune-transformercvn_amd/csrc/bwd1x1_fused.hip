@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd1x1_fused_bf16(const Bwd1x1Args g
                 u16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float t = bf2f(dv[j]) + pP[j] * bf2f(yv[j]) + pQ[j];
+                    const float t = eff3(bf2f(dv[j]), pP[j], bf2f(yv[j]), pQ[j]);
                     o[j] = live ? f2bf(t) : (bf16)0;
                     cs[j] += bf2f(o[j]);
                 }
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(256, 2) void k_bwd1x1_fused_bf16(const Bwd1x1Args g
                         const float u = fmaf(x, csc[j], csh[j]);
                         const float dA = cv[j];
                         const float du = u > 0.f ? dA : csl[j] * dA;
-                        st1[j] += du; st2[j] += du * x; st3[j] += u > 0.f ? 0.f : dA * u;
-                        o[j] = f2bf(bf2f(gv[j]) + csc[j] * du);
+                        st1[j] += du; st2[j] = fmaf(du, x, st2[j]); st3[j] = fmaf(u > 0.f ? 0.f : dA, u, st3[j]);
+                        o[j] = f2bf(fmaf(csc[j], du, bf2f(gv[j])));
                         xa[j] = f2bf(prelu(u, csl[j]));
                     }
                     if (col_rem >= 8) *reinterpret_cast<u16x8*>(gbase + (long)i * 32 * g.ldg + voffG) = o;
@@ -398,10 +398,11 @@ int bwd1x1_fused_launch(const Bwd1x1Args& a, hipStream_t st) {
 
 // the launch's per-workgroup weight-gradient tiles and bias column sums -> dWk [128][ldc], dbias [128] (accumulating); any stream ordered
 // behind the launch -- nothing on the data-gradient chain waits for it
-int bwd1x1_fused_reduce(const Bwd1x1Args& a, float* dWk, float* dbias, const SlabJob* extra, hipStream_t st) {
+int bwd1x1_fused_reduce(const Bwd1x1Args& a, float* dWk, float* dbias, const SlabJob* extra, hipStream_t st, const BnBwdLinkArgs* link) {
     SlabJob jobs[4] = {};
     if (a.M > 0) { jobs[0] = slab_job(a.slab, a.nblk, 128L * a.ldc, dWk, 0); jobs[1] = slab_job(a.tail, a.nblk, 128, dbias, 0); }
     if (extra != nullptr) { jobs[2] = extra[0]; jobs[3] = extra[1]; }          // e.g. the same layer's 3x3 weight-gradient slabs: one launch for both
+    if (link != nullptr) return slab_reduce4_link(jobs, 4, *link, st);         // ... and the norm1 backward link of the layer (round 5)
     return slab_reduce4(jobs, 4, st);
 }
 

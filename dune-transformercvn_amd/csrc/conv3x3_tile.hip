@@ -447,7 +447,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
     };
     if (t0 < t1) fill_rows(0, nrows4, tid, 512);
     if (t0 + 1 < t1) fill_rows(nrows4, TP, tid, 512);
-    if (xf) act_tab_fill(xtab, g.sc, g.sh, g.sl, tid, 512);
+    if (xf && g.lf.isum != nullptr) {                                                  // link-free (round 5): norm2's table from the 1x1 kernel's sums (bn_lf.h)
+        if (tid < 128) {
+            float tsc, tsh;
+            lf_table(g.lf, tid, blockIdx.x == 0, tsc, tsh);
+            xtab[tid] = tsc; xtab[128 + tid] = tsh; xtab[256 + tid] = g.sl[tid];
+        }
+    } else if (xf) act_tab_fill(xtab, g.sc, g.sh, g.sl, tid, 512);
     __syncthreads();
     if (t0 < t1) dma_rows(0, 0, nrows4, wave, 8);
 
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
 #endif
     __syncthreads();                                                                  // the last tile's exchange buffer is complete
     if (roleB && t1 > t0) epilogue(t1 - 1, accp);
-    if (g.part != nullptr) {
+    if (g.part != nullptr || g.isum_out != nullptr) {
         double a = s1, b = s2;
         a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
         if (roleB && lane < 32) { red[(pw * 32 + lane) * 2] = a; red[(pw * 32 + lane) * 2 + 1] = b; }
@@ -632,8 +638,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_fwd_pair_bf16(const ConvFwdA
             double x = 0, y = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { x += red[(w * 32 + tid) * 2]; y += red[(w * 32 + tid) * 2 + 1]; }
-            g.part[((long)blockIdx.x * g.N + tid) * 2] = x;
-            g.part[((long)blockIdx.x * g.N + tid) * 2 + 1] = y;
+            if (g.isum_out != nullptr) lf_add(g.isum_out, g.isum_stride, tid, x, y);                   // link-free: the next consumer derives its table itself
+            else {
+                g.part[((long)blockIdx.x * g.N + tid) * 2] = x;
+                g.part[((long)blockIdx.x * g.N + tid) * 2 + 1] = y;
+            }
         }
     }
 }
@@ -660,9 +669,16 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* smem_base, int off_lo, i
 }
 
 constexpr int WG_RING = 512, WG_TBL = 1024;
-template <bool WRAP>
-__device__ __forceinline__ void wg_kloop(f32x16 (&acc)[9], const char* smem, int base_bytes, const int (&a_lo)[9], const int (&a_hi)[9],
-                                         const char* ebase) {
+// Round 5: the ring carries WG_MIRROR extra rows behind its end that MIRROR its first rows (whoever writes ring row r < WG_MIRROR also writes
+// row WG_RING + r).  A transposed read takes the 16 consecutive rows of a k-step starting anywhere in the ring: with the mirror it never
+// wraps inside an instruction, so its address is (per-lane part, fixed per tap) + (a SCALAR start, one s_and per tap and k-step) -- one VALU
+// add per fragment instead of an add and a mask per read (the multiplying waves issued ~560 instructions per tile around their 72 MFMAs
+// and shared the SIMD's issue slots with the helper wave: 4 800 cycles per tile for 2 300 of matrix work, tools/wgrad_phases.py).  The
+// ring's swizzle moves only the 64-B quad (wswz: row & 3), so rows r and r + 4 -- the two halves of a fragment -- differ by exactly 1 KiB:
+// the second read of a fragment is the first one's address with an immediate offset.
+constexpr int WG_MIRROR = 16, WG_RING_BYTES = (WG_RING + WG_MIRROR) * 256;
+__device__ __forceinline__ int wswz(int r) { return (r & 3) << 2; }
+__device__ __forceinline__ void wg_kloop(f32x16 (&acc)[9], const char* smem, int base_row, const int (&arow0)[9], const int (&lp)[9], const char* ebase) {
     bf16x8_t fr[3][3], fb[2];
     auto issue = [&](int j) {                                       // j = 3 * ks + third
         const int ks = j / 3, third = j - 3 * ks;
@@ -670,9 +686,8 @@ __device__ __forceinline__ void wg_kloop(f32x16 (&acc)[9], const char* smem, int
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int tap = third * 3 + i;
-            if (WRAP) fr[j % 3][i] = tr_frag(smem, (a_lo[tap] + base_bytes + ks * 4096) & (WG_RING * 256 - 1),
-                                             (a_hi[tap] + base_bytes + ks * 4096) & (WG_RING * 256 - 1));
-            else fr[j % 3][i] = tr_frag(smem + base_bytes, a_lo[tap] + ks * 4096, a_hi[tap] + ks * 4096);
+            const int s0 = ((base_row + arow0[tap] + 16 * ks) & (WG_RING - 1)) << 8;      // uniform: scalar ALU
+            fr[j % 3][i] = tr_frag(smem + s0, lp[tap], lp[tap] + 1024);
         }
     };
     constexpr int NG = 3 * (TP / 16);
@@ -703,17 +718,17 @@ __device__ __forceinline__ void wg_kloop(f32x16 (&acc)[9], const char* smem, int
 // issue and 5 100 more until the slice loads queued behind it returned, i.e. the kernel moved its 2.1x redundant image traffic at
 // the HBM rate (3.2 TB/s) while the multiplying waves waited 9 600 of 13 700 cycles at the barrier.
 // Row space of a workgroup: row 0 = padded position t0 * TP - halo; ring slot = row & 511; table entry = row & 1023; the XOR
-// swizzle of a row's 16-B chunks is swz16(row) (tcvn_common.h: a function of row & 15; TP and the ring are multiples of 16, so it
-// equals the tile-relative value).  Round 5: every LDS read of the multiplying waves is a transposed read of four consecutive rows x
-// 64 B; with the forward kernels' `row & 15` swizzle those four rows shared 16 banks (two- to four-way conflicts on all 160 reads
-// per wave and tile: the k loop was LDS-bound at ~5 300 cycles against 2 300 of MFMA issue).
+// swizzle of a row's 16-B chunks is wswz(row) = (row & 3) << 2 (TP and the ring are multiples of 16, so it equals the tile-relative
+// value).  Every LDS read of the multiplying waves is a transposed read of four consecutive rows x 64 B: the forward kernels' `row & 15`
+// swizzle put those four rows on the same 16 banks (two- to four-way conflicts on all 160 reads per wave and tile, rocprofv3 round 4:
+// LDS_BANK_CONFLICT = 2.6 x the LDS-active cycles); with row & 3 selecting the 64-B quad they cover all 64 banks.
 __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradArgs g, int n_img, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvFwdArgs& fa = g.fa;
     const EffSrc& e = g.e;
     const PadGeom q(n_img, fa.H, fa.W);
     const int nrows4 = (q.rows() + 3) & ~3;
-    constexpr int eff_off = WG_RING * 256;                                // two [TP][32] bf16 tiles behind the ring, 64-B rows, unswizzled
+    constexpr int eff_off = WG_RING_BYTES;                                // two [TP][32] bf16 tiles behind the ring (+ mirror rows), 64-B rows, unswizzled
     int* tbl = reinterpret_cast<int*>(smem + eff_off + 2 * TP * 64);      // [1024] pixel index of row (row & 1023)
     float* bred = reinterpret_cast<float*>(smem + eff_off);               // [64][32], aliases the eff tiles after the last barrier
     float* xtab = reinterpret_cast<float*>(smem + eff_off + 2 * TP * 64 + WG_TBL * 4);      // act_fused: [3][128] tables of the image's BatchNorm + PReLU
@@ -765,7 +780,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                 float t = 0.f;
                 const int n = ec * 8 + j;
                 if (m >= 0 && n < e.N) {
-                    t = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
+                    t = eff3(bf2f(gv[j]), cP[j], bf2f(xv[j]), cQ[j]);
                     if (drop) t *= KM != nullptr ? (((kb >> j) & 1u) ? dinv : 0.f)
                                                  : drop_pick(drop_bits32(dkey, m, n, e.N), m, e.drop_p);      // (pixels * N < 2^32: conv3x3_wgrad_tile_ok)
                 }
@@ -792,7 +807,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                 const int rg = w4 + 4 * i;
                 if (rg * 4 < n) {
                     const int row = row0 + rg * 4, rr = row + rsub;       // row0 multiple of 4: the group stays inside the ring
-                    const char* src = mrow[i] >= 0 ? reinterpret_cast<const char*>(YA + (long)mrow[i] * 128) + ((slot ^ swz16(rr)) << 4)
+                    const char* src = mrow[i] >= 0 ? reinterpret_cast<const char*>(YA + (long)mrow[i] * 128) + ((slot ^ wswz(rr)) << 4)
                                                    : zeros + (slot << 4);
                     // the DMA as inline assembly: behind the builtin the compiler orders every later LDS access of this wave (eff tile,
                     // table) behind vmcnt(0) -- it cannot know they touch other rows -- which would put the DMAs last in the iteration with
@@ -800,6 +815,10 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                     const unsigned lds = __builtin_amdgcn_readfirstlane(
                         (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)(smem + (row & (WG_RING - 1)) * 256)));
                     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(src) : "memory");      // (m0 is not allocatable: nothing else in this kernel uses it)
+                    if ((row & (WG_RING - 1)) < WG_MIRROR) {               // the ring's first rows also live behind its end (uniform: row is a multiple of 4)
+                        const unsigned lds2 = lds + WG_RING * 256;
+                        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds2), "v"(src) : "memory");
+                    }
                 }
             }
         };
@@ -822,12 +841,16 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                     const int row = row0 + (in ? rg * 4 : 0) + rsub;
                     mr[j] = tbl[row & (WG_TBL - 1)];
                     if (!in) mr[j] = -1;
-                    p[j] = smem + (row & (WG_RING - 1)) * 256 + ((cc ^ swz16(row)) << 4);
+                    p[j] = smem + (row & (WG_RING - 1)) * 256 + ((cc ^ wswz(row)) << 4);
                     v[j] = *reinterpret_cast<const u16x8*>(p[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (mr[j] >= 0) *reinterpret_cast<u16x8*>(p[j]) = act8_apply(v[j], xtb);
+                    if (mr[j] >= 0) {
+                        const u16x8 o = act8_apply(v[j], xtb);
+                        *reinterpret_cast<u16x8*>(p[j]) = o;
+                        if (p[j] < smem + WG_MIRROR * 256) *reinterpret_cast<u16x8*>(p[j] + WG_RING * 256) = o;      // mirror of the ring's first rows
+                    }
             }
         };
         // With the eff rows materialised by the data-gradient kernel (e.ey): a tile's 128 rows x 64 B arrive by DMA like the image rows,
@@ -883,7 +906,76 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         __syncthreads();                                                    // (2)
         int cur = 0;
         PAIR_T0();
-        if (EYs != nullptr) {
+        if (EYs != nullptr && xf) {
+            // Round 5 (the path the dense blocks 1-2 run).  Per tile the helper moves 128 image rows x 256 B (activated on the way) and 128 eff rows
+            // x 64 B from HBM to LDS.  Requested one tile ahead and waited for in the same iteration (round 4), a helper wave spent ~1 500 of its
+            // 6 100 cycles per tile waiting for those loads, and the multiplying waves waited for the helpers (tools/wgrad_phases.py: k loop 3 800
+            // cycles, barrier 2 700).  Now BOTH travel HBM -> registers TWO tiles ahead (two register sets, the loop unrolled by two): a request has
+            // a whole tile time to arrive, nothing in the loop waits on vmcnt for the current iteration's requests (the barrier needs lgkmcnt
+            // only), the eff tile needs no DMA and its bias sums come from the registers.  32-bit byte offsets against a uniform base (the
+            // launchers bound pixels * 256 B below 4 GB).
+            const int rsub_x = lane >> 4, cc_x = lane & 15;
+            const char* __restrict__ yab = reinterpret_cast<const char*>(YA);
+            const char* __restrict__ eyb = reinterpret_cast<const char*>(EYs);
+            u16x8 rva[10], rvb[10];                                           // [0..7] image chunks, [8..9] eff chunks (rows ra, ra + 64; chunk ec)
+            int ma[10], mb[10];
+            auto fetch = [&](int tl, u16x8 (&rv)[10], int (&rm)[10]) {      // tile tl's 128 new image rows and its 128 eff rows -> registers
+                const int row0 = (tl - 1) * TP + nrows4, body = tl * TP + q.halo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rm[j] = tbl[(row0 + (w4 + 4 * j) * 4 + rsub_x) & (WG_TBL - 1)];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) rm[8 + i] = tbl[(body + ra + 64 * i) & (WG_TBL - 1)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    rv[j] = *reinterpret_cast<const u16x8*>(yab + (size_t)((unsigned)(rm[j] >= 0 ? rm[j] : 0) * 256u + (unsigned)(cc_x * 16)));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    rv[8 + i] = *reinterpret_cast<const u16x8*>(eyb + (size_t)((unsigned)(rm[8 + i] >= 0 ? rm[8 + i] : 0) * 64u + (unsigned)(ec * 16)));
+            };
+            auto commit = [&](int tl, const u16x8 (&rv)[10], const int (&rm)[10]) {      // ... -> the ring (activated) and eff buffer tl & 1
+                const int row0 = (tl - 1) * TP + nrows4;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int row = row0 + (w4 + 4 * j) * 4 + rsub_x;
+                    u16x8 o = act8_apply(rv[j], xtb);
+                    if (rm[j] < 0) o = u16x8{0, 0, 0, 0, 0, 0, 0, 0};                      // padding position: a zero row
+                    char* wp = smem + (row & (WG_RING - 1)) * 256 + ((cc_x ^ wswz(row)) << 4);
+                    *reinterpret_cast<u16x8*>(wp) = o;
+                    if ((row & (WG_RING - 1)) < WG_MIRROR) *reinterpret_cast<u16x8*>(wp + WG_RING * 256) = o;       // mirror of the ring's first rows
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    u16x8 o = rv[8 + i];
+                    if (rm[8 + i] < 0) o = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    *reinterpret_cast<u16x8*>(smem + eff_off + (tl & 1) * TP * 64 + (ra + 64 * i) * 64 + ec * 16) = o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum[j] += bf2f(o[j]);
+                }
+            };
+            if (ntl > 0) bias_from_tile(0);                                 // tile 0's eff rows came by DMA above
+            if (ntl > 1) fetch(1, rva, ma);
+            for (int il = 0; il < ntl; il += 2) {
+                // ---- even half: the multiplying waves work on tile il; set A holds tile il+1 (requested a tile ago) ----
+                if (il + 2 < ntl) fetch(il + 2, rvb, mb);
+                PAIR_PH(8);
+                if (il + 3 < ntl) fill_rows((il + 2) * TP + nrows4, TP);                     // new rows of tile il+3
+                PAIR_PH(10);
+                if (il + 1 < ntl) commit(il + 1, rva, ma);
+                PAIR_PH(13);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // (tile)
+                PAIR_PH(12);
+                if (il + 1 >= ntl) break;
+                // ---- odd half: tile il+1 is multiplied; set B holds tile il+2 ----
+                if (il + 3 < ntl) fetch(il + 3, rva, ma);
+                PAIR_PH(8);
+                if (il + 4 < ntl) fill_rows((il + 3) * TP + nrows4, TP);                     // new rows of tile il+4
+                PAIR_PH(10);
+                if (il + 2 < ntl) commit(il + 2, rvb, mb);
+                PAIR_PH(13);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                PAIR_PH(12);
+            }
+        } else if (EYs != nullptr) {
             // act_fused: the 128 new image rows of tile il+1 travel HBM -> registers (8 x 16 B per lane) instead of HBM -> LDS, are activated in
             // registers and written to the ring once.  The DMA + in-place variant needed an LDS read and a second LDS write per chunk, queued
             // behind the multiplying waves' 160 transposed reads per tile on the one LDS pipe of the CU: 3 200-3 600 cycles per wave and tile
@@ -916,7 +1008,9 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
                         const int row = row0 + (w4 + 4 * j) * 4 + rsub_x;
                         u16x8 o = act8_apply(rv[j], xtb);
                         if (rm[j] < 0) o = u16x8{0, 0, 0, 0, 0, 0, 0, 0};                  // padding position: a zero row
-                        *reinterpret_cast<u16x8*>(smem + (row & (WG_RING - 1)) * 256 + ((cc_x ^ swz16(row)) << 4)) = o;
+                        char* wp = smem + (row & (WG_RING - 1)) * 256 + ((cc_x ^ wswz(row)) << 4);
+                        *reinterpret_cast<u16x8*>(wp) = o;
+                        if ((row & (WG_RING - 1)) < WG_MIRROR) *reinterpret_cast<u16x8*>(wp + WG_RING * 256) = o;       // mirror of the ring's first rows
                     }
                     PAIR_PH(13);
                 }
@@ -968,13 +1062,15 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         const int khalf = gq >> 1, chalf = gq & 1;
         const int a_chunk = w4 * 4 + 2 * chalf + (tp >> 1), a_sub = (tp & 1) * 8;         // Yact: this wave's 32 channels
         const int b_colbyte = (16 * chalf + 4 * tp) * 2;                                  // eff: 32 channels
-        // byte offsets of this lane's two transposed reads per tap at k-step 0, relative to the tile's first image row
-        int a_lo[9], a_hi[9];
+        // a fragment's address = scalar start of its 16-row k-step window (wg_kloop) + this lane's part: row 8*khalf + tq of the window, the
+        // swizzled 16-B chunk (the swizzle takes row & 3: window starts differ from the tile's first row by multiples of 16 plus the tap's
+        // constant shift, so it is fixed per tap) and the 8-B half; the second read of the fragment is 4 rows = 1 KiB further
+        int arow0[9], lp[9];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int arow = q.halo + (tap / 3 - 1) * q.Wp + (tap % 3 - 1) + 8 * khalf + tq, r2 = arow + 4;
-            a_lo[tap] = arow * 256 + ((a_chunk ^ swz16(arow)) << 4) + a_sub;
-            a_hi[tap] = r2 * 256 + ((a_chunk ^ swz16(r2)) << 4) + a_sub;
+            arow0[tap] = q.halo + (tap / 3 - 1) * q.Wp + (tap % 3 - 1);
+            const int arow = arow0[tap] + 8 * khalf + tq;
+            lp[tap] = (8 * khalf + tq) * 256 + ((a_chunk ^ wswz(arow)) << 4) + a_sub;
         }
         const int b_off0 = (8 * khalf + tq) * 64 + b_colbyte;
         __syncthreads();                                                    // (1)
@@ -989,9 +1085,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_bf16(const ConvWgradAr
         for (int t = t0; t < t1; ++t, cur ^= 1) {
             const int base_row = ((t - t0) * TP) & (WG_RING - 1);
             const char* ebase = smem + eff_off + cur * TP * 64 + b_off0;
-            // always the masked addressing: two copies of the loop (immediates where the tile does not cross the ring's end) make the
-            // register allocator spill 700+ registers around the branch
-            wg_kloop<true>(acc, smem, base_row * 256, a_lo, a_hi, ebase);
+            wg_kloop(acc, smem, base_row, arow0, lp, ebase);
             PAIR_PH(0);
             __syncthreads();                                                // (tile)
             PAIR_PH(1);
@@ -1084,7 +1178,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad_bf16(const ConvDgradAr
                     const int n = ec * 8 + j;
                     float v = 0.f;
                     if (n < e.N) {
-                        v = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
+                        v = eff3(bf2f(gv[j]), cP[j], bf2f(xv[j]), cQ[j]);
                         if (drop) v *= drop_pick(drop_bits(dkey, m, n, e.N), m, e.drop_p);
                     }
                     o[j] = f2bf(v);
@@ -1271,7 +1365,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dgrad2_bf16(const ConvDgradA
                 const uint32_t kb = KM != nullptr ? *reinterpret_cast<const uint32_t*>(smem + o_km + rr * 4) >> (ec * 8) : 0u;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float v = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
+                    float v = eff3(bf2f(gv[j]), cP[j], bf2f(xv[j]), cQ[j]);
                     if (drop) v *= KM != nullptr ? (((kb >> j) & 1u) ? dinv : 0.f)
                                                  : drop_pick(drop_bits32(dkey, m, ec * 8 + j, e.N), m, e.drop_p);      // (pixels * N < 2^32: conv3x3_dgrad_tile_ok)
                     o[j] = f2bf(v);
@@ -1446,7 +1540,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_dgrad3_bf16(const ConvDgradA
             const uint32_t kb = kw >> (ec * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float v = bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j];
+                float v = eff3(bf2f(gv[j]), cP[j], bf2f(xv[j]), cQ[j]);
                 if (drop) v *= KM != nullptr ? (((kb >> j) & 1u) ? dinv : 0.f)
                                              : drop_pick(drop_bits32(dkey, m, ec * 8 + j, e.N), m, e.drop_p);      // (pixels * N < 2^32: launcher)
                 o[j] = f2bf(v);
@@ -1601,7 +1695,7 @@ int tile_grid2(long ntiles) {           // two workgroups per CU
 }
 
 // ring + two eff tiles + table; the ring must hold a tile's rows and the 128 rows being fetched for the next one
-size_t wgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return r4 + TP + 8 <= 512 ? size_t(512) * 256 + 2 * TP * 64 + 1024 * 4 + 3 * 128 * 4 : size_t(1) << 30; }
+size_t wgrad_smem(const PadGeom& q) { const size_t r4 = (q.rows() + 3) & ~3; return r4 + TP + 8 <= 512 ? size_t(WG_RING_BYTES) + 2 * TP * 64 + 1024 * 4 + 3 * 128 * 4 : size_t(1) << 30; }
 
 int tile_grid(long ntiles) {            // one persistent workgroup per CU
     [[maybe_unused]] static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
@@ -1646,6 +1740,11 @@ bool conv3x3_act_fusable(const ConvFwdArgs& a) {
     // forward: only the pair kernel activates in LDS; backward: the weight-gradient tile kernel (same geometry conditions as conv3x3_wgrad_tile_ok)
     return !off && fwd_pair_ok(a, q, dbg) && wgrad_smem(q) <= 160 * 1024;
 }
+bool conv3x3_fwd_pair(const ConvFwdArgs& a) {          // conv_fwd(a) runs k_conv3x3_fwd_pair_bf16 (the kernel that honours lf / isum_out)
+    if (!conv3x3_tile_ok(a)) return false;
+    [[maybe_unused]] static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
+    return fwd_pair_ok(a, PadGeom(a.M / (a.H * a.W), a.H, a.W), dbg);
+}
 bool conv3x3_fwd_writes_keep(const ConvFwdArgs& a) {
     if (a.keep_out == nullptr || a.drop_p <= 0.f || !conv3x3_tile_ok(a)) return false;
     [[maybe_unused]] static const int dbg = TCVN_KNOB_INT("TCVN_DBG");
@@ -1678,6 +1777,7 @@ int conv3x3_fwd_tile(const ConvFwdArgs& a, hipStream_t st) {
         TCVN_LAUNCH_CHECK();
         return 0;
     }
+    if (a.lf.isum != nullptr || a.isum_out != nullptr) return -2;            // only the pair kernel derives / adds link-free statistics (conv3x3_fwd_pair)
     if (!a.act_fused && ((q.rows() + 3) & ~3) + TP <= RING && !TCVN_DBG_BIT(dbg, 32)) {       // consecutive tiles per workgroup, ring image (TCVN_DBG=32: strips)
         static bool attr2 = false;
         if (!attr2) {

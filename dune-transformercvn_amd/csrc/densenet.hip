@@ -130,6 +130,18 @@ void DenseNetPlan::layout(int n, bool bwd, Layout& L) const {
     L.c0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
     L.D.clear(); L.Y.clear(); L.bstatD.clear(); L.bstatY.clear(); L.YA.clear(); L.XA.clear(); L.XP.clear(); L.KM.clear();
     L.zeros = b.take(1024);
+    // link-free statistics accumulators: contiguous with the zero page, so that ONE memset per forward clears both
+    L.isumD.clear(); L.isumY.clear(); L.isum_bytes = 0;
+    if (cfg.mode == MODE_BF16) {
+        const long i0 = b.off;
+        for (const auto& bg : blocks) {
+            L.isumD.push_back(b.take((long)LF_REP * bg.ld * 16));             // LF_REP replicas of [ld][2]
+            std::vector<long> ys;
+            for (int l = 0; l < bg.L; ++l) ys.push_back(b.take((long)LF_REP * mid * 16));
+            L.isumY.push_back(ys);
+        }
+        L.isum_bytes = b.off - i0;
+    }
     L.sact = (cfg.mode == MODE_BF16 && cfg.init_ch == 64) ? b.take((long)n * Hc * stem_act_words(Wc) * 4) : -1;
     L.sidx = sparse_stem_possible() ? b.take(stem_sparse_index_bytes(n, cfg.H, cfg.W)) : -1;
     long max_part = (long)pool0_grid(n, blocks[0].H, blocks[0].W) * cfg.init_ch * 16;
@@ -368,9 +380,10 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
     if (!train && (rc = bn_eval_tables(d_bn, n_bneval, kEps, st))) return rc;
 
     auto link = [&](const BnSlots& s, const double* prt, int nblk, int part_ld, int c_new0, int n_new, double* bstat,
-                    long count) -> int {
+                    long count, const long long* isum = nullptr, long isum_stride = 0) -> int {
         if (!train) return 0;
-        BnLinkArgs a;
+        BnLinkArgs a{};
+        a.isum = isum; a.isum_stride = isum_stride;                  // window sums in fixed-point accumulators (a link-free producer) instead of partial rows
         a.part = prt; a.nblk = nblk; a.part_ld = part_ld; a.c_new0 = c_new0; a.n_new = n_new; a.bstat = bstat;
         a.count = count; a.C = s.C; a.gamma = data[s.w]; a.beta = data[s.b];
         a.running_mean = data[s.rm]; a.running_var = data[s.rv];
@@ -379,7 +392,19 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
     };
 
     // ---- stem ----
-    TCVN_CHECK(hipMemsetAsync(ws + L.zeros, 0, 1024, st));
+    // Round 5, link-free BatchNorm statistics (bn_lf.h): the fused 1x1 kernels and the 3x3 pair kernel ADD their per-workgroup sums to
+    // fixed-point accumulators and derive their input BatchNorm's table in their own prologue -- no k_bn_link launch between them (120 of
+    // the 132 per step and embedder).  TCVN_NO_LF (validation build): the link kernels of rounds 1-4.
+    static const bool no_lf = TCVN_KNOB_SET("TCVN_NO_LF");
+    const bool lf_on = train && !no_lf && mode == MODE_BF16 && L.isum_bytes > 0;
+    TCVN_CHECK(hipMemsetAsync(ws + L.zeros, 0, 1024 + (lf_on ? L.isum_bytes : 0), st));
+    auto lf_of = [&](const BnSlots& s, const long long* isum, long rep_stride, int c_new0, int n_new, double* bstat, long count) {
+        LfLink k{};
+        k.isum = isum; k.rep_stride = rep_stride; k.c_new0 = c_new0; k.n_new = n_new; k.bstat = bstat; k.inv_count = 1.0 / (double)count; k.count = count;
+        k.gamma = data[s.w]; k.beta = data[s.b]; k.running_mean = data[s.rm]; k.running_var = data[s.rv];
+        Tab t = tab(s); k.sc_out = t.sc; k.sh_out = t.sh; k.eps = kEps; k.momentum = kMom;
+        return k;
+    };
     // Sparse-aware stem (bf16, 3 -> 64 channels, the hit list fits the index): conv0 + BN0 + PReLU0 + AvgPool straight from the COO
     // list, neither the dense map nor the conv0 output is materialised (stem_sparse.hip).  Otherwise: scatter + dense kernels.
     // Measured on MI355X (256 prong maps / 32 event maps, round 3): inference -- index + pooled pass 0.60 / 0.27 ms against 0.97 / 0.12 ms
@@ -469,9 +494,10 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
         char* D = ws + L.D[bi];
         double* bstatD = reinterpret_cast<double*>(ws + L.bstatD[bi]);
         int new_c0 = 0, new_n = bg.C0, new_nblk = init_nblk, new_ld = init_ld;   // channels whose stats are fresh in `part`
+        long long* isumD = lf_on ? reinterpret_cast<long long*>(ws + L.isumD[bi]) : nullptr;      // [ld][2], indexed by channel
+        bool new_isum = false;                                                    // ... or in isumD (added there by a link-free producer)
         for (int l = 0; l < bg.L; ++l) {
             const LayerSlots& ls = bg.layers[l];
-            if ((rc = link(ls.n1, part, new_nblk, new_ld, new_c0, new_n, bstatD, M))) return rc;
             const bool fast1 = L.XA[bi][l] >= 0;
             const int cin8 = (int)round_up(ls.cin, 8);
             // Eval mode (running statistics: no batch reduction between the 1x1 output and its BatchNorm): the 1x1 GEMM's epilogue
@@ -493,6 +519,12 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             // the fused 1x1 backward kernel rebuilds that activation from x, so the activated copy XA is neither written nor read.
             static const bool no_fuse1 = TCVN_KNOB_SET("TCVN_NO_FWD1_FUSE") || TCVN_KNOB_SET("TCVN_NO_BWD1_FUSE");
             static const bool no_wide1 = TCVN_KNOB_SET("TCVN_NO_FWD1_WIDE");         // validation build: wide layers on k_act_bf16 + the 128-row GEMM
+            bool lf2 = false;                  // the 3x3 pair kernel derives norm2's table itself (no link launch in front of it)
+            bool n1_linked = false;
+            auto link_n1 = [&]() -> int {      // norm1's table by the link kernel (window sums from the partial rows or from isumD)
+                n1_linked = true;
+                return link(ls.n1, part, new_nblk, new_ld, new_c0, new_n, bstatD, M, new_isum ? isumD + 2 * new_c0 : nullptr, 2L * bg.ld);
+            };
             if ((train || fuse_ya) && fast1 && !no_fuse1 && mid == 128 && mode == MODE_BF16 && !(no_wide1 && wk_find(ls.w1, 0, 1).Kp > 256)) {
                 const WkEntry& e = wk_find(ls.w1, 0, 1);
                 Tab t1 = tab(ls.n1);
@@ -507,12 +539,30 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 // train mode: the activated copy XA is only dropped when the backward's fused 1x1 kernel will accept this layer (it rebuilds
                 // the activation from x); otherwise the step would die in backward after the forward has already run
                 if (fwd1x1_fused_ok(fa) && (!train || bwd1x1_fusable((int)bi, l, M, ws, L))) {
+                    long long* isumY = lf_on ? reinterpret_cast<long long*>(ws + L.isumY[bi][l]) : nullptr;
+                    // link-free consumer of norm1: the fresh window was added to isumD by the previous layer's 3x3 kernel (the block's first
+                    // layer follows a transition / the stem, whose statistics still leave as partial rows: link kernel)
+                    static const bool lf_no1 = TCVN_KNOB_SET("TCVN_LF_NO1"), lf_no2 = TCVN_KNOB_SET("TCVN_LF_NO2");      // validation build: the link kernel
+                    if (lf_on && new_isum && !lf_no1) fa.lf = lf_of(ls.n1, isumD + 2 * new_c0, 2L * bg.ld, new_c0, new_n, bstatD, M);
+                    else if ((rc = link_n1())) return rc;
+                    fa.isum_out = isumY; fa.isum_stride = 2L * mid;       // link-free producer of norm2's statistics
                     if ((rc = fwd1x1_fused(fa, st))) return rc;
-                    if ((rc = link(ls.n2, part, fa.nblk, mid, 0, mid, reinterpret_cast<double*>(ws + L.bstatY[bi][l]), M))) return rc;
+                    // norm2's consumer: the 3x3 pair kernel with the activation in LDS derives the table itself; anything else takes the link kernel
+                    if (isumY != nullptr) {
+                        ConvFwdArgs c3{};
+                        c3.mode = mode; c3.amode = A_3X3; c3.A = ws + L.Y[bi][l]; c3.lda = mid; c3.M = (int)M; c3.N = g; c3.K = 9 * mid;
+                        c3.Kp = wk_find(ls.w2, 0).Kp; c3.C = mid; c3.H = bg.H; c3.W = bg.W; c3.Wk = ws + L.wk + wk_find(ls.w2, 0).off;
+                        c3.Wfrag = wk_frag(ws, L, ls.w2, 0); c3.Aact = ws + L.Y[bi][l]; c3.zeros = ws + L.zeros;
+                        Tab t2 = tab(ls.n2);
+                        c3.sc = t2.sc; c3.sh = t2.sh; c3.sl = data[ls.a2];
+                        lf2 = conv3x3_act_fusable(c3) && conv3x3_fwd_pair(c3) && !lf_no2;
+                    }
+                    if (!lf2 && (rc = link(ls.n2, part, fa.nblk, mid, 0, mid, reinterpret_cast<double*>(ws + L.bstatY[bi][l]), M, isumY, 2L * mid))) return rc;
                     xa_skipped[bi][l] = 1;
                     goto conv3;
                 }
             }
+            if (!n1_linked && (rc = link_n1())) return rc;
             if (fast1 && xa_materialize()) {     // activated copy of the 1x1 input: operand of the bf16 GEMMs (forward, weight gradient)
                 Tab t1 = tab(ls.n1);
                 ActArgs act{D, bg.ld, M, ls.cin, t1.sc, t1.sh, data[ls.a1], ws + L.XA[bi][l], cin8};
@@ -575,6 +625,12 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                 a.part = train ? part : nullptr;
                 a.drop_p = train ? cfg.dropout : 0.f; a.seed = seed; a.stream_id = (uint32_t)(bi * 64 + l + 1);
                 a.nblk = conv_fwd_nblk(a);
+                if (lf2) {                     // (decided above on the same arguments: pair kernel + in-LDS activation)
+                    if (!a.act_fused) { fprintf(stderr, "tcvn: link-free norm2 without the in-LDS activation\n"); return -17; }
+                    a.lf = lf_of(ls.n2, reinterpret_cast<long long*>(ws + L.isumY[bi][l]), 2L * mid, 0, mid, reinterpret_cast<double*>(ws + L.bstatY[bi][l]), M);
+                }
+                const bool out_isum = lf_on && mode == MODE_BF16 && conv3x3_fwd_pair(a) && g <= 32;      // link-free producer of the new channels' statistics
+                if (out_isum) { a.isum_out = isumD + 2 * ls.cin; a.isum_stride = 2L * bg.ld; }
                 if (train && !L.KM[bi].empty()) {           // the pair kernel leaves the keep flags it drew for the backward kernels
                     a.keep_out = reinterpret_cast<uint32_t*>(ws + L.KM[bi][l]);
                     if (keep_valid.size() != blocks.size()) keep_valid.assign(blocks.size(), std::vector<char>());
@@ -582,12 +638,12 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
                     keep_valid[bi][l] = conv3x3_fwd_writes_keep(a) ? 1 : 0;
                 }
                 if ((rc = conv_fwd(a, st))) return rc;
-                new_c0 = ls.cin; new_n = g; new_nblk = a.nblk; new_ld = g;
+                new_c0 = ls.cin; new_n = g; new_nblk = a.nblk; new_ld = g; new_isum = out_isum;
             }
         }
         if (bg.has_trans) {
             const BlockGeom& nb = blocks[bi + 1];
-            if ((rc = link(bg.tn, part, new_nblk, new_ld, new_c0, new_n, bstatD, M))) return rc;
+            if ((rc = link(bg.tn, part, new_nblk, new_ld, new_c0, new_n, bstatD, M, new_isum ? isumD + 2 * new_c0 : nullptr, 2L * bg.ld))) return rc;
             const WkEntry& e = wk_find(bg.tw, 0);
             Tab t = tab(bg.tn);
             const long Mn = (long)n * nb.H * nb.W;
@@ -619,7 +675,7 @@ int DenseNetPlan::forward(int n, const int32_t* coords, const float* values, lon
             if ((rc = conv_fwd(a, st))) return rc;
             init_nblk = a.nblk; init_ld = bg.Ctot / 2;
         } else {
-            if ((rc = link(nf, part, new_nblk, new_ld, new_c0, new_n, bstatD, M))) return rc;
+            if ((rc = link(nf, part, new_nblk, new_ld, new_c0, new_n, bstatD, M, new_isum ? isumD + 2 * new_c0 : nullptr, 2L * bg.ld))) return rc;
             Tab t = tab(nf);
             HeadPoolArgs a{mode, D, bg.ld, n, bg.H * bg.W, Cf, t.sc, t.sh, data[s_af], reinterpret_cast<float*>(ws + L.F)};
             if ((rc = head_pool_fwd(a, st))) return rc;
@@ -651,6 +707,13 @@ int DenseNetPlan::tap(int n, const char* name, long* off, int* tn, int* th, int*
     if (s == "condense") { *off = L.F; *th = 1; *tw = 1; *tc = Cf; *tld = Cf; *tes = 4; return 0; }
     if (s == "raw:wk") { *tn = *th = *tw = 1; *off = L.wk; *tc = *tld = (int)(wk_bytes() / esz); return 0; }
     if (s == "raw:tabs") { *tn = *th = *tw = 1; *off = L.tabs; *tc = *tld = (int)tab_floats(); *tes = 4; return 0; }
+    if (s.rfind("raw:ystat", 0) == 0) {                          // (mean, biased var) of a bottleneck map: "raw:ystat<block>.<layer>"
+        int b = 0, l = 0;
+        if (sscanf(s.c_str(), "raw:ystat%d.%d", &b, &l) != 2) return -1;
+        b -= 1;
+        if (b < 0 || b >= (int)blocks.size() || l < 0 || l >= blocks[b].L) return -1;
+        *tn = *th = *tw = 1; *off = L.bstatY[b][l]; *tc = *tld = 2 * cfg.bn_size * cfg.growth; *tes = 8; return 0;
+    }
     if (s.rfind("raw:bstat", 0) == 0) {
         const int b = atoi(s.c_str() + 9) - 1;
         if (b < 0 || b >= (int)blocks.size()) return -1;

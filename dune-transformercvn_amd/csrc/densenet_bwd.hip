@@ -336,8 +336,17 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 // The slab reductions stay on `st` behind the launch (on the side stream, with double-buffered slabs, the step was 0.25 ms LONGER);
                 // one launch reduces this kernel's slabs and the 3x3 weight gradient's.
                 if ((rc = bwd1x1_fused_launch(fa, st))) return rc;
-                if ((rc = bwd1x1_fused_reduce(fa, gw_of(ls.w1), grad[ls.b1], w3_deferred ? w3jobs : nullptr, st))) return rc;
-                if ((rc = bwd_link(ls.n1, fa.nblk, bstatD, M, P, Q, 1, ls.a1))) return rc;
+                // Round 5: the norm1 link rides in the reduction launch (an extra z-plane of k_slab_reduce_link): both are ~5 us latency-floor
+                // launches on the critical chain and independent of each other -- 60 launches fewer per step (TCVN_SPLIT_LINK: two launches)
+                static const bool split_link = TCVN_KNOB_SET("TCVN_SPLIT_LINK");
+                if (split_link) {
+                    if ((rc = bwd1x1_fused_reduce(fa, gw_of(ls.w1), grad[ls.b1], w3_deferred ? w3jobs : nullptr, st))) return rc;
+                    if ((rc = bwd_link(ls.n1, fa.nblk, bstatD, M, P, Q, 1, ls.a1))) return rc;
+                } else {
+                    const BnSlots& s1 = ls.n1;
+                    BnBwdLinkArgs la{part, fa.nblk, s1.C, bstatD, M, kEps, data[s1.w], grad[s1.w], grad[s1.b], grad[ls.a1], P, Q, 1};
+                    if ((rc = bwd1x1_fused_reduce(fa, gw_of(ls.w1), grad[ls.b1], w3_deferred ? w3jobs : nullptr, st, &la))) return rc;
+                }
                 continue;
             }
             if (bi < (int)xa_skipped.size() && l < (int)xa_skipped[bi].size() && xa_skipped[bi][l]) {

@@ -28,6 +28,9 @@ struct Layout {
     std::vector<std::vector<long>> EY3;               // bf16 mode: [pixels][32] eff rows of a layer's 3x3 output gradient (data gradient -> weight gradient)
     std::vector<std::vector<long>> KM;                // bf16 mode with dropout: one keep word per pixel and dense layer (3x3 output dropout)
     long zeros, ey, ey2, slab;
+    long isum_bytes = 0;                 // link-free BatchNorm statistics (bn_lf.h): fixed-point accumulators, directly behind the zero page
+    std::vector<long> isumD;             //   per dense block: [ld][2] int64 (sum, sum of squares) of the concat buffer's channels
+    std::vector<std::vector<long>> isumY;    //   per dense layer: [128][2] of the bottleneck map
     long slab1;                          // bf16 mode: slabs of the fused 1x1 backward kernel (main stream; `slab` may be in use by the 3x3 weight gradient
                                          // on the side stream when tcvn_backward_overlap is on)
     long sact;                           // bf16 dense stem: activity bitmap of the conv0 output (stem_mark), -1 when unused

@@ -20,7 +20,15 @@ __global__ __launch_bounds__(256) void k_bn_link(const BnLinkArgs a) {
     const float rmean = upd || !a.train ? a.running_mean[c] : 0.f, rvar = upd || !a.train ? a.running_var[c] : 0.f;
     double mean, var;
     if (a.train) {
-        if (c >= a.c_new0 && c < a.c_new0 + a.n_new) {
+        if (c >= a.c_new0 && c < a.c_new0 + a.n_new && a.isum != nullptr) {
+            // the producer added its sums to fixed-point accumulators (bn_lf.h): nothing to reduce
+            long long sa, sb;
+            lf_sums(a.isum, a.isum_stride, c - a.c_new0, sa, sb);
+            mean = (double)sa * ((1.0 / (double)a.count) / LF_S1);
+            var = (double)sb * ((1.0 / (double)a.count) / LF_S2) - mean * mean;
+            if (var < 0) var = 0;
+            if (lane == 0) { a.bstat[c * 2] = mean; a.bstat[c * 2 + 1] = var; }
+        } else if (c >= a.c_new0 && c < a.c_new0 + a.n_new) {
             double s1 = 0, s2 = 0;
             // eight partial rows per trip: every row of a launch with <= 512 workgroups in one round trip (see k_bn_bwd_link)
             for (int b = lane; b < a.nblk; b += 512) {

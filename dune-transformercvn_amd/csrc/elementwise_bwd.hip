@@ -9,9 +9,9 @@ namespace {
 //   s1 = sum dU, t2 = sum dU*x, s3 = sum dA*min(u,0)   (partials from the dgrad epilogue / pooling backward kernels)
 //   dbeta = s1 ; dgamma = sum dU*xhat = r*(t2 - mu*s1) ; dslope = s3
 //   dx = sc*dU + Px*x + Qx  with  Px = -sc*dgamma*r/M ,  Qx = -sc*s1/M + sc*dgamma*r*mu/M      (sc = gamma*r)
-__global__ __launch_bounds__(256) void k_bn_bwd_link(const BnBwdLinkArgs a) {
+__device__ __forceinline__ void bn_bwd_link_body(const BnBwdLinkArgs& a, int blk) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + wave;
+    const int c = blk * 4 + wave;
     if (c >= a.C) return;
     // everything the closing arithmetic needs is requested up front, with the partial rows (one round trip instead of two: see k_bn_link)
     const double mu = a.bstat[c * 2], var = a.bstat[c * 2 + 1];
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_link(const BnBwdLinkArgs a) {
     const float Qx = (float)(-sc * s1 / M + sc * dgamma * r * mu / M);
     a.P[c] = p_old + Px; a.Q[c] = q_old + Qx;
 }
+__global__ __launch_bounds__(256) void k_bn_bwd_link(const BnBwdLinkArgs a) { bn_bwd_link_body(a, blockIdx.x); }
 
 // global-average head backward: dz = dF/HW on every pixel, then PReLU+BN backward bookkeeping of final_norm
 constexpr int HP_CJ = 4;     // up to 1024 channels with 256 threads
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a, int wlog) {
             u16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float t = tx * 8 + j < e.N ? bf2f(gv[j]) + cP[j] * bf2f(xv[j]) + cQ[j] : 0.f;
+                float t = tx * 8 + j < e.N ? eff3(bf2f(gv[j]), cP[j], bf2f(xv[j]), cQ[j]) : 0.f;
                 if (e.drop_p > 0.f) t *= drop_pick(drop_bits(dkey, m, tx * 8 + j, e.N), m, e.drop_p);
                 o[j] = f2bf(t);
                 cs[j] += bf2f(o[j]);
@@ -187,10 +188,8 @@ __global__ __launch_bounds__(256) void k_eff_mat(const EffMatArgs a, int wlog) {
 // dst[i] += sum_s slab[s*stride + i]: block = 64 columns x 4 slab lanes; grid.y splits the slabs (<= 16 atomics per element);
 // grid.z selects one of two independent jobs (e.g. a weight-gradient slab and the bias column sums of the same layer: one
 // launch instead of two -- these launches sit at the ~5 us dispatch floor)
-__global__ __launch_bounds__(256) void k_slab_reduce(const SlabJob j0, const SlabJob j1, const SlabJob j2, const SlabJob j3) {
-    const SlabJob& j = blockIdx.z == 0 ? j0 : blockIdx.z == 1 ? j1 : blockIdx.z == 2 ? j2 : j3;
+__device__ __forceinline__ void slab_reduce_body(const SlabJob& j, float (*red)[256]) {
     if (j.count <= 0) return;
-    __shared__ __attribute__((aligned(16))) float red[4][256];
     const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
     if ((int)blockIdx.y >= j.ny) return;                                               // uniform per workgroup
     const int s0 = blockIdx.y * j.per_y, s1 = min(j.nslab, s0 + j.per_y);
@@ -238,6 +237,22 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const SlabJob j0, const Sla
         const float v = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
         if (j.ny == 1) j.dst[i] += v; else atomicAdd(j.dst + i, v);
     }
+}
+__global__ __launch_bounds__(256) void k_slab_reduce(const SlabJob j0, const SlabJob j1, const SlabJob j2, const SlabJob j3) {
+    __shared__ __attribute__((aligned(16))) float red[4][256];
+    slab_reduce_body(blockIdx.z == 0 ? j0 : blockIdx.z == 1 ? j1 : blockIdx.z == 2 ? j2 : j3, red);
+}
+// The same launch with one more z-plane that runs a BatchNorm backward link (round 5): after the fused 1x1 backward kernel both its slab
+// reduction and the norm1 link are ~5 us latency-floor launches on the critical chain, independent of each other (different inputs, different
+// outputs) -- one launch instead of two per dense layer.  Plane `nz` = the link: its first cdiv(C, 4) workgroups of y-slice 0.
+__global__ __launch_bounds__(256) void k_slab_reduce_link(const SlabJob j0, const SlabJob j1, const SlabJob j2, const SlabJob j3, int nz,
+                                                          const BnBwdLinkArgs link) {
+    __shared__ __attribute__((aligned(16))) float red[4][256];
+    if ((int)blockIdx.z == nz) {
+        if (blockIdx.y == 0) bn_bwd_link_body(link, blockIdx.x);
+        return;
+    }
+    slab_reduce_body(blockIdx.z == 0 ? j0 : blockIdx.z == 1 ? j1 : blockIdx.z == 2 ? j2 : j3, red);
 }
 
 __global__ void k_unpack(const UnpackDesc* descs) {
@@ -322,6 +337,19 @@ int slab_reduce4(const SlabJob* jobs, int n, hipStream_t st) {
     }
     if (nz == 0) return 0;
     hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)gmax, nymax, nz), dim3(256), 0, st, j[0], j[1], j[2], j[3]);
+    TCVN_LAUNCH_CHECK();
+    return 0;
+}
+int slab_reduce4_link(const SlabJob* jobs, int n, const BnBwdLinkArgs& link, hipStream_t st) {
+    SlabJob j[4] = {};
+    long gmax = cdiv(link.C, 4); int nymax = 1, nz = 0;
+    for (int i = 0; i < n && i < 4; ++i) {
+        if (jobs[i].count <= 0) continue;
+        j[nz++] = jobs[i];
+        const long g = cdiv(jobs[i].count, jobs[i].v4 ? 256 : 64);
+        gmax = g > gmax ? g : gmax; nymax = jobs[i].ny > nymax ? jobs[i].ny : nymax;
+    }
+    hipLaunchKernelGGL(k_slab_reduce_link, dim3((unsigned)gmax, nymax, nz + 1), dim3(256), 0, st, j[0], j[1], j[2], j[3], nz, link);
     TCVN_LAUNCH_CHECK();
     return 0;
 }

@@ -57,7 +57,12 @@ __global__ __launch_bounds__(256, 3) void k_fwd1x1_fused_bf16(const Fwd1x1Args g
     }
     for (int i = tid; i < NKC * 128; i += 256) {
         const bool ok = i < K;
-        tab[i] = ok ? g.sc[i] : 0.f; tab[NKC * 128 + i] = ok ? g.sh[i] : 0.f; tab[2 * NKC * 128 + i] = ok ? g.sl[i] : 0.f;
+        float tsc = 0.f, tsh = 0.f;
+        if (ok) {
+            if (g.lf.isum != nullptr) lf_table(g.lf, i, blockIdx.x == 0, tsc, tsh);      // link-free: norm1's table from the producers' sums (bn_lf.h)
+            else { tsc = g.sc[i]; tsh = g.sh[i]; }
+        }
+        tab[i] = tsc; tab[NKC * 128 + i] = tsh; tab[2 * NKC * 128 + i] = ok ? g.sl[i] : 0.f;
     }
     const int ocol = (tid >> 6) * 32 + (tid & 31);                         // this lane's output column in MFMA layout: wave*32 + (lane & 31)
     const float cbias = g.bias[ocol];
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd1x1_fused_bf16(const Fwd1x1Args g
         // (the next iteration's first barrier separates this read of Cs from the next tile's write)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (g.part == nullptr) return;
+    if (g.part == nullptr && g.isum_out == nullptr) return;
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, c8 = tid & 15;
 #pragma unroll
@@ -220,8 +225,8 @@ __global__ __launch_bounds__(256, 3) void k_fwd1x1_fused_bf16(const Fwd1x1Args g
         double a = 0, b = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { a += red[(w * 128 + tid) * 2]; b += red[(w * 128 + tid) * 2 + 1]; }
-        double* p = g.part + ((long)blockIdx.x * 128 + tid) * 2;
-        p[0] = a; p[1] = b;
+        if (g.isum_out != nullptr) lf_add(g.isum_out, g.isum_stride, tid, a, b);          // link-free: the consumer derives norm2's table itself (bn_lf.h)
+        else { double* p = g.part + ((long)blockIdx.x * 128 + tid) * 2; p[0] = a; p[1] = b; }
     }
 }
 
@@ -251,6 +256,17 @@ __global__ __launch_bounds__(256, 2) void k_fwd1x1_wide_bf16(const Fwd1x1Args g)
     const long mtiles = (g.M + ROWS - 1) / ROWS;
     const int ksteps = g.Kp >> 4;
 
+    // the table first (link-free: fp64 arithmetic on the producers' sums), THEN the 32 weight fragments: with the fragments' 128 destination
+    // registers already live the table code spilled 21 more registers into the tile loop
+    for (int i = tid; i < 512; i += 256) {
+        const bool ok = i < K;
+        float tsc = 0.f, tsh = 0.f;
+        if (ok) {
+            if (g.lf.isum != nullptr) lf_table(g.lf, i, blockIdx.x == 0, tsc, tsh);      // link-free: norm1's table from the producers' sums (bn_lf.h)
+            else { tsc = g.sc[i]; tsh = g.sh[i]; }
+        }
+        tab[i] = tsc; tab[512 + i] = tsh; tab[1024 + i] = ok ? g.sl[i] : 0.f;
+    }
     bf16x8_t bw[KS];
     {
         const bf16* __restrict__ Wf = reinterpret_cast<const bf16*>(g.Wfrag) + (((long)(tid >> 6) * ksteps) * 64 + (tid & 63)) * 8;
@@ -261,10 +277,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd1x1_wide_bf16(const Fwd1x1Args g)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bw[i][j] = (__bf16)0.f;
         }
-    }
-    for (int i = tid; i < 512; i += 256) {
-        const bool ok = i < K;
-        tab[i] = ok ? g.sc[i] : 0.f; tab[512 + i] = ok ? g.sh[i] : 0.f; tab[1024 + i] = ok ? g.sl[i] : 0.f;
     }
     const int ocol = (tid >> 6) * 32 + (tid & 31);
     const float cbias = g.bias[ocol];
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd1x1_wide_bf16(const Fwd1x1Args g)
         // (the next tile's C tile is written three barriers from here)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (g.part == nullptr) return;
+    if (g.part == nullptr && g.isum_out == nullptr) return;
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, c8 = tid & 15;
 #pragma unroll
@@ -405,15 +417,18 @@ __global__ __launch_bounds__(256, 2) void k_fwd1x1_wide_bf16(const Fwd1x1Args g)
         double a = 0, b = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { a += red[(w * 128 + tid) * 2]; b += red[(w * 128 + tid) * 2 + 1]; }
-        double* p = g.part + ((long)blockIdx.x * 128 + tid) * 2;
-        p[0] = a; p[1] = b;
+        if (g.isum_out != nullptr) lf_add(g.isum_out, g.isum_stride, tid, a, b);          // link-free: the consumer derives norm2's table itself (bn_lf.h)
+        else { double* p = g.part + ((long)blockIdx.x * 128 + tid) * 2; p[0] = a; p[1] = b; }
     }
 }
 
 }  // namespace
 
 bool fwd1x1_fused_ok(const Fwd1x1Args& a) {
-    if (!a.Xin || !a.Out || !a.Wfrag || !a.zeros || !a.bias || !a.sc || !a.sh || !a.sl) return false;
+    if (!a.Xin || !a.Out || !a.Wfrag || !a.zeros || !a.bias || !a.sl) return false;
+    if (a.lf.isum == nullptr && (!a.sc || !a.sh)) return false;
+    if (a.lf.isum != nullptr && (!a.lf.bstat || !a.lf.gamma || !a.lf.beta || !a.lf.sc_out || !a.lf.sh_out || a.lf.count <= 0)) return false;
+    if (a.isum_out != nullptr && a.osc != nullptr) return false;
     if (a.osc != nullptr && (a.part != nullptr || !a.osh || !a.osl)) return false;      // the output activation is the eval-mode epilogue: no statistics
     if (a.cin <= 0 || a.cin > 512 || a.Kp < a.cin || a.Kp > 512 || (a.Kp & 15) || (a.ldx & 7) || a.ldx < a.cin) return false;
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.Xin) | reinterpret_cast<uintptr_t>(a.Out) | reinterpret_cast<uintptr_t>(a.Wfrag);
@@ -429,7 +444,7 @@ int fwd1x1_fused_nblk(const Fwd1x1Args& a) {
 int fwd1x1_fused(const Fwd1x1Args& a, hipStream_t st) {
     if (a.M <= 0) return 0;
     if (!fwd1x1_fused_ok(a)) return -2;
-    if (a.part != nullptr && a.nblk != fwd1x1_fused_nblk(a)) { fprintf(stderr, "tcvn: fwd1x1_fused nblk mismatch\n"); return -3; }
+    if (a.part != nullptr && a.isum_out == nullptr && a.nblk != fwd1x1_fused_nblk(a)) { fprintf(stderr, "tcvn: fwd1x1_fused nblk mismatch\n"); return -3; }
     static bool attr = false;
     if (!attr) {
         const void* fns[4] = {reinterpret_cast<const void*>(k_fwd1x1_fused_bf16<1, false>), reinterpret_cast<const void*>(k_fwd1x1_fused_bf16<2, false>),

@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256, ROWS == 64 ? 2 : 1) void k_gemm_nt_bf16(const 
                             const float u = fmaf(x, csc[j], csh[j]);
                             const float dA = cv[j];
                             const float du = u > 0.f ? dA : csl[j] * dA;
-                            f1[j] += du; f2[j] += du * x; f3[j] += u > 0.f ? 0.f : dA * u;
-                            o[j] = ncol + j < g.N ? f2bf(bf2f(gv[j]) + csc[j] * du) : gv[j];   // beyond N: not ours
+                            f1[j] += du; f2[j] = fmaf(du, x, f2[j]); f3[j] = fmaf(u > 0.f ? 0.f : dA, u, f3[j]);
+                            o[j] = ncol + j < g.N ? f2bf(fmaf(csc[j], du, bf2f(gv[j]))) : gv[j];   // beyond N: not ours
                         }
                         *reinterpret_cast<u16x8*>(gp) = o;
                     }

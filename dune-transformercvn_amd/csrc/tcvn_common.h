@@ -46,6 +46,11 @@ template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return f2bf(
 template <typename T> __device__ __forceinline__ float round_to(float v) { return to_f<T>(from_f<T>(v)); }
 
 __device__ __forceinline__ float prelu(float u, float a) { return u > 0.f ? u : a * u; }
+// The effective gradient g + P*x + Q and the gradient accumulation g + s*d with the FMA spelled out: left as `a + b*c` the compiler
+// contracts or not depending on the surrounding code (an unrelated edit of the fused 1x1 backward epilogue un-fused four of its eight
+// G updates: kernels that must agree bit for bit -- the fused backward and the three kernels it replaces -- then differed by an fp32 ulp
+// in front of a bf16 rounding, 4e-3 in the stem's gradients).
+__device__ __forceinline__ float eff3(float g, float P, float x, float Q) { return fmaf(P, x, g) + Q; }
 
 // XOR swizzle of the sixteen 16-B chunks of a 256-B LDS row that is read BOTH ways: slot = chunk ^ swz16(row).  Row-wise b128 fragment reads
 // (16 consecutive rows, one chunk) need a bijection of row & 15 onto the slots; the transposed reads (ds_read_b64_tr_b16: half a wave = four

@@ -1,6 +1,7 @@
 // Internal host-side launch interface of the gfx950 kernels (the public C-ABI in include/tcvn_hip.h wraps these).
 #pragma once
 #include "tcvn_common.h"
+#include "bn_lf.h"
 
 namespace tcvn {
 
@@ -32,8 +33,14 @@ struct ConvFwdArgs {
     uint32_t* keep_out;              // optional [M]: the 3x3 pair kernel stores the keep flags of a pixel's N <= 32 channels as one word
     int act_fused;                   // bf16 3x3 tile kernels (forward pair kernel, weight gradient): Aact is the RAW [pixels][128] map; the wave that
                                      // fetched a row applies prelu(sc*x + sh, sl) to it in LDS, once, before any tap reads it -- no activated copy in HBM
+    LfLink lf;                       // forward pair kernel with act_fused (round 5): lf.isum != nullptr -> the (sc, sh) table of the image's BatchNorm is
+                                     // derived in the prologue from the producer's fixed-point sums (bn_lf.h); sc / sh are then not read
+    long long* isum_out; long isum_stride;   // forward pair kernel: when set, the statistics of the N output channels are ADDED to replica
+                                     // (blockIdx.x % LF_REP) of isum_out[n][2] (fixed point, bn_lf.h; replicas isum_stride long longs apart) instead of
+                                     // leaving as a partial row in `part`
 };
 int conv_fwd(const ConvFwdArgs& a, hipStream_t st);
+bool conv3x3_fwd_pair(const ConvFwdArgs& a);          // true when conv_fwd(a) runs the pair kernel (the one that honours ConvFwdArgs::lf / isum_out)
 bool conv3x3_fwd_writes_keep(const ConvFwdArgs& a);   // true when conv_fwd(a) runs the kernel that fills keep_out
 bool conv3x3_act_fusable(const ConvFwdArgs& a);       // true when both the forward kernel conv_fwd(a) would run and the weight-gradient tile kernel of the
                                                       // same layer can take the raw map (ConvFwdArgs::act_fused)
@@ -60,6 +67,8 @@ struct BnLinkArgs {
     float *running_mean, *running_var;           // updated when `train`
     float *sc, *sh;                              // outputs [C]
     int train; float eps, momentum;
+    const long long* isum; long isum_stride;     // optional: the window's sums come from fixed-point accumulators (bn_lf.h: LF_REP replicas of
+                                                 // [n_new][2], isum_stride long longs apart, added by a producer with lf_add) instead of the partial rows
 };
 int bn_link(const BnLinkArgs& a, hipStream_t st);
 
@@ -184,6 +193,7 @@ struct BnBwdLinkArgs {
     float *P, *Q; int accumulate_pq;
 };
 int bn_bwd_link(const BnBwdLinkArgs& a, hipStream_t st);
+int slab_reduce4_link(const SlabJob* jobs, int n, const BnBwdLinkArgs& link, hipStream_t st);   // up to four slab reductions + one link in ONE launch
 
 // head: dF[img][c] -> G of the last block (+ partials);  stem tail: eff of block-1's first channels -> DU0 (+ partials)
 struct HeadPoolBwdArgs {
@@ -261,7 +271,7 @@ struct Bwd1x1Args {
 bool bwd1x1_fused_ok(const Bwd1x1Args& a);
 int bwd1x1_fused_nblk(const Bwd1x1Args& a);
 int bwd1x1_fused_launch(const Bwd1x1Args& a, hipStream_t st);
-int bwd1x1_fused_reduce(const Bwd1x1Args& a, float* dWk, float* dbias, const SlabJob* extra, hipStream_t st);   // slab reductions into dWk [128][ldc], dbias [128]
+int bwd1x1_fused_reduce(const Bwd1x1Args& a, float* dWk, float* dbias, const SlabJob* extra, hipStream_t st, const BnBwdLinkArgs* link = nullptr);   // slab reductions into dWk [128][ldc], dbias [128]
                                                                                                   // (+ up to two more jobs in the same launch)
 
 // Forward of a bottleneck 1x1 convolution on the RAW concat buffer (fwd1x1_fused.hip): norm1 + PReLU1 applied to the landed LDS tiles,
@@ -275,6 +285,10 @@ struct Fwd1x1Args {
     const float *osc, *osh, *osl;           // optional (eval mode, part == nullptr): Out = prelu(osc*(C + bias) + osh, osl) -- norm2 (running statistics) + PReLU2
     const void* zeros;
     double* part; int nblk;                 // [nblk][128][2] or null; nblk = fwd1x1_fused_nblk()
+    LfLink lf;                              // round 5: lf.isum != nullptr -> norm1's (sc, sh) table is derived in the prologue from fixed-point sums
+                                            // (bn_lf.h) and published by workgroup 0; sc / sh are then not read
+    long long* isum_out; long isum_stride;  // when set (train mode): Y's statistics are ADDED to replica (blockIdx.x % LF_REP) of isum_out[128][2]
+                                            // (fixed point, replicas isum_stride long longs apart) instead of `part`
 };
 bool fwd1x1_fused_ok(const Fwd1x1Args& a);
 int fwd1x1_fused_nblk(const Fwd1x1Args& a);
