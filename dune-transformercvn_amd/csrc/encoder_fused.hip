@@ -71,10 +71,16 @@ __device__ __forceinline__ void gemm_t64(const float* dy, int ldy, int n0, int g
 }
 // mask[s][c] = dropout keep-scale of element (t = s*B + b, c) of a [T][D] site
 __device__ __forceinline__ void fill_mask(float* mask, int S, int B, int b, float dp, uint64_t seed, uint32_t sid) {
+    // a thread draws four consecutive columns of a row = the four words of one Philox call (the row's first index (s*B + b)*128 is a multiple of 4)
 #pragma unroll 1
-    for (int i = threadIdx.x; i < S * D; i += 256) {
-        const int s = i >> 7, c = i & 127;
-        mask[i] = drop_scale(dp, seed, sid, ((uint64_t)s * B + b) * D + c);
+    for (int i = threadIdx.x; i < S * (D / 4); i += 256) {
+        const int s = i >> 5, c = (i & 31) * 4;
+        DropCache dc{~0ull, {0, 0, 0, 0}};
+        const uint64_t e0 = ((uint64_t)s * B + b) * D + c;
+        f32x4 m;
+        m.x = drop_scale_cached(dc, dp, seed, sid, e0); m.y = drop_scale_cached(dc, dp, seed, sid, e0 + 1);
+        m.z = drop_scale_cached(dc, dp, seed, sid, e0 + 2); m.w = drop_scale_cached(dc, dp, seed, sid, e0 + 3);
+        *reinterpret_cast<f32x4*>(mask + s * D + c) = m;
     }
 }
 
@@ -179,11 +185,12 @@ __global__ __launch_bounds__(256, 1) void k_encoder_fwd(const EncFusedArgs a) {
 #pragma unroll
             for (int e = 0; e < HD; ++e) cx[e] = 0.f;
             float* P = a.save ? O.probs + (((long)b * H + h) * S + s) * S : nullptr;
+            DropCache dc{~0ull, {0, 0, 0, 0}};
 #pragma unroll 1
             for (int j = 0; j < S; ++j) {
                 float pr = p[j] * inv;
                 if (P) P[j] = pr;
-                if (dp > 0.f) pr *= drop_scale(dp, a.seed, sid, (((uint64_t)b * H + h) * S + s) * S + j);
+                if (dp > 0.f) pr *= drop_scale_cached(dc, dp, a.seed, sid, (((uint64_t)b * H + h) * S + s) * S + j);
                 const float* v = qkv + j * QLD + 2 * D + h * HD;
 #pragma unroll
                 for (int e = 0; e < HD; ++e) cx[e] = fmaf(pr, v[e], cx[e]);
@@ -396,6 +403,7 @@ __global__ __launch_bounds__(256, 1) void k_encoder_bwd(const EncFusedBwdArgs a)
             float* rS = xS + (h * SMAX + s) * (SMAX + 1);
             float* rP = xP + (h * SMAX + s) * (SMAX + 1);
             float dot = 0.f;
+            DropCache dcc{~0ull, {0, 0, 0, 0}};
 #pragma unroll 1
             for (int j = 0; j < S; ++j) {
                 const float* v = bQ + j * QLD + 2 * D + h * HD;
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void k_encoder_bwd(const EncFusedBwdArgs a)
 #pragma unroll
                 for (int e = 0; e < HD; ++e) gsum = fmaf(dc[e], v[e], gsum);
                 float m = 1.f;
-                if (dp > 0.f) m = drop_scale(dp, a.seed, sid, (((uint64_t)b * H + h) * S + s) * S + j);
+                if (dp > 0.f) m = drop_scale_cached(dcc, dp, a.seed, sid, (((uint64_t)b * H + h) * S + s) * S + j);
                 const float pj = P[j];
                 rP[j] = pj * m;
                 const float dpj = gsum * m;

@@ -50,9 +50,12 @@ HBn HeadPlan::add_bn(const std::string& p, int c) {
 HeadPlan::HeadPlan(const tcvn_head_cfg& c) : cfg(c) {
     const int D = cfg.hidden_dim;
     const std::string ce = "prong_embedding.combined_embedding";
+    // LinearBlock (layers/prong_feature_embedding.py:7-33): Linear(bias = not linear_batch_norm) - BatchNorm1d | Identity - PReLU | ReLU - Dropout
+    const bool bn = !cfg.no_linear_bn, prelu_act = !cfg.linear_relu;
     cw = add_slot(ce + ".linear.weight", (long)D * cfg.in_dim, TCVN_SLOT_PARAM);
-    cn = add_bn(ce + ".norm", D);
-    ca = add_slot(ce + ".activation.weight", D, TCVN_SLOT_PARAM);
+    if (!bn) cb = add_slot(ce + ".linear.bias", D, TCVN_SLOT_PARAM);
+    if (bn) cn = add_bn(ce + ".norm", D);
+    if (prelu_act) ca = add_slot(ce + ".activation.weight", D, TCVN_SLOT_PARAM);
     for (int l = 0; l < cfg.n_layers; ++l) {
         const std::string p = "encoder.encoder.layers." + std::to_string(l);
         HLayer L;
@@ -77,11 +80,12 @@ HeadPlan::HeadPlan(const tcvn_head_cfg& c) : cfg(c) {
         const std::string p = "prong_decoder.hidden_layers.";
         HDec d;
         d.in = in; d.out = cfg.dec_dims[i];
+        // create_linear_block (layers/encoder.py:10-24): [Linear, BatchNorm1d?, PReLU | ReLU, Dropout?] -- the Sequential indices follow
         d.w = add_slot(p + std::to_string(idx) + ".weight", (long)d.out * d.in, TCVN_SLOT_PARAM);
         d.b = add_slot(p + std::to_string(idx) + ".bias", d.out, TCVN_SLOT_PARAM);
-        d.n = add_bn(p + std::to_string(idx + 1), d.out);
-        d.a = add_slot(p + std::to_string(idx + 2) + ".weight", d.out, TCVN_SLOT_PARAM);
-        idx += 3 + (cfg.dropout_modules ? 1 : 0);
+        if (bn) d.n = add_bn(p + std::to_string(idx + 1), d.out);
+        if (prelu_act) d.a = add_slot(p + std::to_string(idx + 1 + (bn ? 1 : 0)) + ".weight", d.out, TCVN_SLOT_PARAM);
+        idx += 2 + (bn ? 1 : 0) + (cfg.dropout_modules ? 1 : 0);
         in = d.out;
         dec.push_back(d);
     }
@@ -146,10 +150,11 @@ int HeadPlan::embed(int B, int P, int nP, const float* rows, const int32_t* tok_
     const float dp = train ? cfg.dropout : 0.f;
     auto F = [&](long off) { return reinterpret_cast<float*>(ws + off); };
     int rc;
-    if ((rc = linear_fwd(rows, cfg.in_dim, data[cw], nullptr, F(L.Zc), D, R, D, cfg.in_dim, st))) return rc;
+    if ((rc = linear_fwd(rows, cfg.in_dim, data[cw], cb >= 0 ? data[cb] : nullptr, F(L.Zc), D, R, D, cfg.in_dim, st))) return rc;
     RowsBnArgs r{};
-    r.X = F(L.Zc); r.ldx = D; r.R = R; r.C = D; r.gamma = data[cn.w]; r.beta = data[cn.b]; r.slope = data[ca];
-    r.running_mean = data[cn.rm]; r.running_var = data[cn.rv]; r.Y = F(L.C); r.ldy = D;
+    r.X = F(L.Zc); r.ldx = D; r.R = R; r.C = D; r.slope = ca >= 0 ? data[ca] : nullptr; r.no_norm = cfg.no_linear_bn;
+    if (!r.no_norm) { r.gamma = data[cn.w]; r.beta = data[cn.b]; r.running_mean = data[cn.rm]; r.running_var = data[cn.rv]; }
+    r.Y = F(L.C); r.ldy = D;
     r.save_mean = F(L.cstat); r.save_rstd = F(L.cstat) + D; r.train = train; r.eps = kEps; r.momentum = kMom;
     r.drop_p = dp; r.seed = seed; r.stream_id = 0x5000u;
     if ((rc = rows_bn_fwd(r, st))) return rc;
@@ -235,8 +240,9 @@ int HeadPlan::decode(int B, int P, float* ev_logits, float* pr_logits, char* ws,
         const HDec& d = dec[i];
         if ((rc = linear_fwd(in, inw, data[d.w], data[d.b], F(L.Zd[i]), d.out, TP, d.out, d.in, st))) return rc;
         RowsBnArgs r{};
-        r.X = F(L.Zd[i]); r.ldx = d.out; r.R = TP; r.C = d.out; r.gamma = data[d.n.w]; r.beta = data[d.n.b]; r.slope = data[d.a];
-        r.running_mean = data[d.n.rm]; r.running_var = data[d.n.rv]; r.Y = F(L.Ad[i]); r.ldy = d.out;
+        r.X = F(L.Zd[i]); r.ldx = d.out; r.R = TP; r.C = d.out; r.slope = d.a >= 0 ? data[d.a] : nullptr; r.no_norm = cfg.no_linear_bn;
+        if (!r.no_norm) { r.gamma = data[d.n.w]; r.beta = data[d.n.b]; r.running_mean = data[d.n.rm]; r.running_var = data[d.n.rv]; }
+        r.Y = F(L.Ad[i]); r.ldy = d.out;
         r.save_mean = F(L.dstat[i]); r.save_rstd = F(L.dstat[i]) + d.out; r.train = train; r.eps = kEps; r.momentum = kMom;
         r.drop_p = cfg.dropout_modules ? dp : 0.f; r.seed = seed; r.stream_id = 0x7000u + (uint32_t)i;
         if ((rc = rows_bn_fwd(r, st))) return rc;
@@ -305,8 +311,10 @@ int HeadPlan::backward(int B, int P, int nP, const float* rows, const int32_t* t
         const HDec& d = dec[i];
         RowsBnBwdArgs r{};
         r.X = F(L.Zd[i]); r.ldx = d.out; r.dY = dA; r.lddy = d.out; r.R = TP; r.C = d.out;
-        r.gamma = data[d.n.w]; r.beta = data[d.n.b]; r.slope = data[d.a]; r.save_mean = F(L.dstat[i]); r.save_rstd = F(L.dstat[i]) + d.out;
-        r.dX = dZ; r.lddx = d.out; r.dgamma = grad[d.n.w]; r.dbeta = grad[d.n.b]; r.dslope = grad[d.a];
+        r.no_norm = cfg.no_linear_bn; r.slope = d.a >= 0 ? data[d.a] : nullptr; r.dslope = d.a >= 0 ? grad[d.a] : nullptr;
+        if (!r.no_norm) { r.gamma = data[d.n.w]; r.beta = data[d.n.b]; r.dgamma = grad[d.n.w]; r.dbeta = grad[d.n.b]; }
+        r.save_mean = F(L.dstat[i]); r.save_rstd = F(L.dstat[i]) + d.out;
+        r.dX = dZ; r.lddx = d.out;
         r.drop_p = cfg.dropout_modules ? dp : 0.f; r.seed = seed; r.stream_id = 0x7000u + (uint32_t)i;
         if ((rc = rows_bn_bwd(r, st))) return rc;
         const float* in = i == 0 ? F(L.HID) + (long)B * D : F(L.Ad[i - 1]);
@@ -409,12 +417,14 @@ combined:
     {
         RowsBnBwdArgs r{};
         r.X = F(L.Zc); r.ldx = D; r.dY = F(L.dC); r.lddy = D; r.R = R; r.C = D;
-        r.gamma = data[cn.w]; r.beta = data[cn.b]; r.slope = data[ca]; r.save_mean = F(L.cstat); r.save_rstd = F(L.cstat) + D;
-        r.dX = F(L.dZc); r.lddx = D; r.dgamma = grad[cn.w]; r.dbeta = grad[cn.b]; r.dslope = grad[ca];
+        r.no_norm = cfg.no_linear_bn; r.slope = ca >= 0 ? data[ca] : nullptr; r.dslope = ca >= 0 ? grad[ca] : nullptr;
+        if (!r.no_norm) { r.gamma = data[cn.w]; r.beta = data[cn.b]; r.dgamma = grad[cn.w]; r.dbeta = grad[cn.b]; }
+        r.save_mean = F(L.cstat); r.save_rstd = F(L.cstat) + D;
+        r.dX = F(L.dZc); r.lddx = D;
         r.drop_p = dp; r.seed = seed; r.stream_id = 0x5000u;
         if ((rc = rows_bn_bwd(r, st))) return rc;
     }
-    if ((rc = linear_bwd_dw(F(L.dZc), D, rows, cfg.in_dim, grad[cw], nullptr, R, D, cfg.in_dim, st))) return rc;
+    if ((rc = linear_bwd_dw(F(L.dZc), D, rows, cfg.in_dim, grad[cw], cb >= 0 ? grad[cb] : nullptr, R, D, cfg.in_dim, st))) return rc;
     return linear_bwd_dx(F(L.dZc), D, data[cw], d_rows, cfg.in_dim, R, D, cfg.in_dim, 0, st);
 }
 
@@ -514,11 +524,14 @@ extern "C" int tcvn_rows_bn_prelu_forward(const float* x, int64_t ldx, int rows,
                                           const float* slope, float* running_mean, float* running_var, float* y, int64_t ldy,
                                           float* save_mean_rstd, int train, float drop_p, uint64_t seed, uint32_t stream_id,
                                           void* stream) {
-    if (!x || !y || !gamma || !beta || !slope || !running_mean || !running_var || !save_mean_rstd || rows <= 0 || channels <= 0) return -1;
+    const bool no_norm = !gamma && !beta && !running_mean && !running_var;      // LinearBlock without BatchNorm1d (norm = Identity)
+    if (!x || !y || rows <= 0 || channels <= 0) return -1;
+    if (!no_norm && (!gamma || !beta || !running_mean || !running_var || !save_mean_rstd)) return -1;
     RowsBnArgs r{};
-    r.X = x; r.ldx = ldx; r.R = rows; r.C = channels; r.gamma = gamma; r.beta = beta; r.slope = slope;
+    r.no_norm = no_norm ? 1 : 0;
+    r.X = x; r.ldx = ldx; r.R = rows; r.C = channels; r.gamma = gamma; r.beta = beta; r.slope = slope;      // slope NULL: ReLU
     r.running_mean = running_mean; r.running_var = running_var; r.Y = y; r.ldy = ldy;
-    r.save_mean = save_mean_rstd; r.save_rstd = save_mean_rstd + channels; r.train = train; r.eps = kEps; r.momentum = kMom;
+    r.save_mean = save_mean_rstd; r.save_rstd = save_mean_rstd ? save_mean_rstd + channels : nullptr; r.train = train; r.eps = kEps; r.momentum = kMom;
     r.drop_p = train ? drop_p : 0.f; r.seed = seed; r.stream_id = stream_id;
     return rows_bn_fwd(r, reinterpret_cast<hipStream_t>(stream));
 }
@@ -537,10 +550,13 @@ extern "C" int tcvn_rows_bn_prelu_backward(const float* x, int64_t ldx, const fl
                                            const float* gamma, const float* beta, const float* slope, const float* save_mean_rstd,
                                            float* dx, int64_t lddx, float* dgamma, float* dbeta, float* dslope, float drop_p,
                                            uint64_t seed, uint32_t stream_id, void* stream) {
-    if (!x || !dy || !gamma || !beta || !slope || !save_mean_rstd || !dx || !dgamma || !dbeta || !dslope || rows <= 0 || channels <= 0) return -1;
+    const bool no_norm = !gamma && !beta && !dgamma && !dbeta;                  // LinearBlock without BatchNorm1d
+    if (!x || !dy || !dx || rows <= 0 || channels <= 0 || (slope != nullptr) != (dslope != nullptr)) return -1;
+    if (!no_norm && (!gamma || !beta || !save_mean_rstd || !dgamma || !dbeta)) return -1;
     RowsBnBwdArgs r{};
+    r.no_norm = no_norm ? 1 : 0;
     r.X = x; r.ldx = ldx; r.dY = dy; r.lddy = lddy; r.R = rows; r.C = channels; r.gamma = gamma; r.beta = beta; r.slope = slope;
-    r.save_mean = save_mean_rstd; r.save_rstd = save_mean_rstd + channels; r.dX = dx; r.lddx = lddx;
+    r.save_mean = save_mean_rstd; r.save_rstd = save_mean_rstd ? save_mean_rstd + channels : nullptr; r.dX = dx; r.lddx = lddx;
     r.dgamma = dgamma; r.dbeta = dbeta; r.dslope = dslope; r.drop_p = drop_p; r.seed = seed; r.stream_id = stream_id;
     return rows_bn_bwd(r, reinterpret_cast<hipStream_t>(stream));
 }

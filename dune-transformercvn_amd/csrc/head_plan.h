@@ -9,9 +9,9 @@
 
 namespace tcvn {
 
-struct HBn { int w, b, rm, rv; };
+struct HBn { int w = -1, b = -1, rm = -1, rv = -1; };
 struct HLayer { int win, bin, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2; };
-struct HDec { int w, b, a, in, out; HBn n; };
+struct HDec { int w, b, a = -1, in, out; HBn n; };      // a = -1: ReLU; n.w = -1: no BatchNorm1d
 struct HLayBuf { long qkv, probs, ctx, ao, xh1, rstd1, x1, hpre, hact, f, xh2, rstd2, g_dqkv, g_dao, g_dhp, g_df,
                  h1, h2; };     // h1 / h2: LayerNorm outputs of the pre-norm variant (transformer_norm_first)
 struct HLayout {
@@ -24,7 +24,7 @@ struct HeadPlan {
     tcvn_head_cfg cfg;
     std::vector<Slot> slots;
     std::vector<float*> data, grad;
-    int cw, ca, ew, eb, ow, ob, dec_width;
+    int cw, cb = -1, ca = -1, ew, eb, ow, ob, dec_width;      // cb: combined linear bias (only without BatchNorm1d); ca: PReLU slope (-1: ReLU)
     HBn cn;
     std::vector<HLayer> layers;
     std::vector<HDec> dec;

@@ -53,6 +53,16 @@ __global__ __launch_bounds__(256) void k_rows_bn_fwd(const RowsBnArgs a) {
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;      // 16 columns x 16 row lanes per workgroup
     const int c = blockIdx.x * 16 + cl;
     const bool ok = c < a.C;
+    if (a.no_norm) {                                          // LinearBlock without BatchNorm1d: activation + dropout only
+        if (!ok) return;
+        const float sl = a.slope ? a.slope[c] : 0.f;
+        for (int r = rg; r < a.R; r += 16) {
+            float z = prelu(a.X[(long)r * a.ldx + c], sl);
+            if (a.train && a.drop_p > 0.f) z *= drop_scale(a.drop_p, a.seed, a.stream_id, (uint64_t)r * a.C + c);
+            a.Y[(long)r * a.ldy + c] = z;
+        }
+        return;
+    }
     if (a.train) {
         double s1 = 0, s2 = 0;
         if (ok)
@@ -98,6 +108,26 @@ __global__ __launch_bounds__(256) void k_rows_bn_bwd(const RowsBnBwdArgs a) {
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;      // 16 columns x 16 row lanes per workgroup
     const int c = blockIdx.x * 16 + cl;
     const bool ok = c < a.C;
+    if (a.no_norm) {                                          // no BatchNorm1d in the block: element-wise backward + the slope's column sum
+        const float sl = (ok && a.slope) ? a.slope[c] : 0.f;
+        double s3 = 0;
+        if (ok)
+            for (int r = rg; r < a.R; r += 16) {
+                const float u = a.X[(long)r * a.ldx + c];
+                float dz = a.dY[(long)r * a.lddy + c];
+                if (a.drop_p > 0.f) dz *= drop_scale(a.drop_p, a.seed, a.stream_id, (uint64_t)r * a.C + c);
+                if (a.dX) a.dX[(long)r * a.lddx + c] = u > 0.f ? dz : sl * dz;
+                s3 += u > 0.f ? 0.f : dz * u;
+            }
+        red[rg][cl][0] = s3;
+        __syncthreads();
+        if (rg == 0 && ok && a.dslope) {
+            double z = 0;
+            for (int q = 0; q < 16; ++q) z += red[q][cl][0];
+            a.dslope[c] += (float)z;
+        }
+        return;
+    }
     const float mean = ok ? a.save_mean[c] : 0.f, rstd = ok ? a.save_rstd[c] : 0.f;
     const float g = (ok && a.gamma) ? a.gamma[c] : 1.f, b = (ok && a.beta) ? a.beta[c] : 0.f;
     const float sl = (ok && a.slope) ? a.slope[c] : 0.f;

@@ -99,6 +99,20 @@ __device__ __forceinline__ float drop_scale(float p, uint64_t seed, uint32_t str
     if (p <= 0.f) return 1.f;
     return rng_uniform(seed, stream, idx) >= p ? 1.f / (1.f - p) : 0.f;
 }
+// The same draws for callers that walk consecutive element indices: elements 4q .. 4q+3 are the four words of ONE Philox call (counter q), so
+// the call is repeated only when idx >> 2 changes (a Philox-4x32-10 is 40 quarter-rate integer multiplies; the fused encoder spent ~20 % of
+// its time recomputing the same block four times).  `cur` / `r` are the caller's cache (cur = ~0 initially).
+struct DropCache { uint64_t cur; uint4 r; };
+__device__ __forceinline__ float drop_scale_cached(DropCache& dc, float p, uint64_t seed, uint32_t stream, uint64_t idx) {
+    if (p <= 0.f) return 1.f;
+    const uint64_t q = idx >> 2;
+    if (q != dc.cur) {
+        dc.r = philox4((uint32_t)q, (uint32_t)(q >> 32), stream, 0x5443564eu, (uint32_t)seed, (uint32_t)(seed >> 32));
+        dc.cur = q;
+    }
+    const uint32_t w = (idx & 3) == 0 ? dc.r.x : (idx & 3) == 1 ? dc.r.y : (idx & 3) == 2 ? dc.r.z : dc.r.w;
+    return (w >> 8) * (1.0f / 16777216.0f) >= p ? 1.f / (1.f - p) : 0.f;
+}
 
 // Dropout mask of a [pixels, N] activation slice.  Counter-based and stateless (recomputed in backward): one 32-bit
 // avalanche hash (lowbias32) per (pixel pair, channel) yields two 16-bit uniform draws; pixel & 1 selects the draw, so

@@ -36,6 +36,8 @@ struct RowsBnArgs {
     float *save_mean, *save_rstd;
     int train; float eps, momentum;
     float drop_p; uint64_t seed; uint32_t stream_id;
+    int no_norm;                 // options.linear_batch_norm == False: no BatchNorm1d in the block (norm = Identity): Y = drop(act(X));
+                                 // slope == nullptr is ReLU (options.linear_prelu_activation == False)
 };
 int rows_bn_fwd(const RowsBnArgs& a, hipStream_t st);
 
@@ -46,6 +48,7 @@ struct RowsBnBwdArgs {
     float* dX; long lddx;
     float *dgamma, *dbeta, *dslope;
     float drop_p; uint64_t seed; uint32_t stream_id;
+    int no_norm;                 // as in RowsBnArgs: dX = act'(X) * drop * dY, no batch terms (dslope may be null: ReLU)
 };
 int rows_bn_bwd(const RowsBnBwdArgs& a, hipStream_t st);
 

@@ -38,7 +38,8 @@ class HeadCfg(C.Structure):
     _fields_ = [("hidden_dim", C.c_int), ("heads", C.c_int), ("n_layers", C.c_int), ("in_dim", C.c_int),
                 ("event_classes", C.c_int), ("prong_classes", C.c_int), ("n_dec", C.c_int), ("dec_dims", C.c_int * 8),
                 ("dec_out_in", C.c_int), ("gelu", C.c_int), ("norm_first", C.c_int), ("dropout_modules", C.c_int),
-                ("dropout", C.c_float), ("gamma", C.c_float), ("event_weight", C.c_float)]
+                ("dropout", C.c_float), ("gamma", C.c_float), ("event_weight", C.c_float),
+                ("no_linear_bn", C.c_int), ("linear_relu", C.c_int)]
 
 
 def _load():

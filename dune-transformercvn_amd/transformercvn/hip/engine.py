@@ -172,7 +172,8 @@ class HeadEngine(_Plan):
     _prefix = "head"
 
     def __init__(self, hidden_dim: int, heads: int, n_layers: int, in_dim: int, event_classes: int, prong_classes: int,
-                 dec_dims, dec_out_in: int, gelu: bool, norm_first: bool, dropout: float, gamma: float, event_weight: float):
+                 dec_dims, dec_out_in: int, gelu: bool, norm_first: bool, dropout: float, gamma: float, event_weight: float,
+                 linear_batch_norm: bool = True, linear_prelu_activation: bool = True):
         super().__init__()
         cfg = _lib.HeadCfg()
         cfg.hidden_dim, cfg.heads, cfg.n_layers, cfg.in_dim = hidden_dim, heads, n_layers, in_dim
@@ -183,6 +184,8 @@ class HeadEngine(_Plan):
         cfg.dec_out_in, cfg.gelu, cfg.norm_first = dec_out_in, int(gelu), int(norm_first)
         cfg.dropout_modules = int(dropout > 0.0)
         cfg.dropout, cfg.gamma, cfg.event_weight = dropout, gamma, event_weight
+        # LinearBlock option variants (reference layers/prong_feature_embedding.py:11-21, layers/encoder.py:13-19)
+        cfg.no_linear_bn, cfg.linear_relu = int(not linear_batch_norm), int(not linear_prelu_activation)
         self.cfg = cfg
         check(lib.tcvn_head_create(C.byref(cfg), C.byref(self.handle)), "head_create")
         self._shape = (0, 0, 0)

@@ -34,27 +34,37 @@ def linear(x: Tensor, weight: Tensor, bias: Tensor = None) -> Tensor:
     return y
 
 
-def bn_prelu(x: Tensor, norm: nn.BatchNorm1d, slope: Tensor, training: bool, drop_p: float = 0.0, seed: int = 0,
-             stream_id: int = 0) -> Tensor:
-    """dropout(prelu(batchnorm1d(x))) over rows; updates the module's running statistics in training mode."""
+def _p(t) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _norm_of(norm):
+    """(BatchNorm1d or None): the reference's LinearBlock has nn.Identity() in its place when options.linear_batch_norm is False."""
+    return norm if isinstance(norm, nn.BatchNorm1d) else None
+
+
+def bn_prelu(x: Tensor, norm, slope, training: bool, drop_p: float = 0.0, seed: int = 0, stream_id: int = 0) -> Tensor:
+    """dropout(act(norm(x))) over rows: norm = BatchNorm1d (running statistics updated in training mode) or None / nn.Identity (option
+    linear_batch_norm False); slope = the PReLU weight or None for ReLU (option linear_prelu_activation False)."""
     _need_cuda(x, "BatchNorm1d-PReLU")
     x = x.detach().float().contiguous()
     rows, ch = x.shape
     y = torch.empty_like(x)
+    norm = _norm_of(norm)
     scratch = torch.empty(2 * ch, device=x.device)
-    check(lib.tcvn_rows_bn_prelu_forward(C.c_void_p(x.data_ptr()), x.stride(0), rows, ch, C.c_void_p(norm.weight.data_ptr()),
-                                         C.c_void_p(norm.bias.data_ptr()), C.c_void_p(slope.data_ptr()),
-                                         C.c_void_p(norm.running_mean.data_ptr()), C.c_void_p(norm.running_var.data_ptr()),
-                                         C.c_void_p(y.data_ptr()), y.stride(0), C.c_void_p(scratch.data_ptr()), int(training),
-                                         float(drop_p), C.c_uint64(seed), C.c_uint32(stream_id), _st()), "rows_bn_prelu_forward")
-    if training:
+    check(lib.tcvn_rows_bn_prelu_forward(C.c_void_p(x.data_ptr()), x.stride(0), rows, ch, _p(norm.weight if norm else None),
+                                         _p(norm.bias if norm else None), _p(slope), _p(norm.running_mean if norm else None),
+                                         _p(norm.running_var if norm else None), C.c_void_p(y.data_ptr()), y.stride(0),
+                                         C.c_void_p(scratch.data_ptr()), int(training), float(drop_p), C.c_uint64(seed),
+                                         C.c_uint32(stream_id), _st()), "rows_bn_prelu_forward")
+    if training and norm is not None:
         norm.num_batches_tracked += 1
     return y
 
 
 class FeatureMLP:
     """Forward / backward of ``ProngFeatureEmbedding.embedding`` (a chain of LinearBlocks: Linear(no bias) - BatchNorm1d - PReLU -
-    Dropout, reference layers/prong_feature_embedding.py:36-78) on the HIP row kernels, inside the fused training step: the
+    Dropout, or their option variants Linear(bias) - Identity / ReLU; reference layers/prong_feature_embedding.py:7-33, :36-78) on the HIP row kernels, inside the fused training step: the
     forward keeps what the backward needs, the backward accumulates parameter gradients into the runtime's gradient arena views."""
 
     def __init__(self, blocks):
@@ -70,13 +80,14 @@ class FeatureMLP:
             y = torch.empty_like(z)
             stat = torch.empty(2 * ch, device=z.device)
             p = float(blk.dropout.p) if training else 0.0
-            check(lib.tcvn_rows_bn_prelu_forward(C.c_void_p(z.data_ptr()), z.stride(0), rows, ch, C.c_void_p(blk.norm.weight.data_ptr()),
-                                                 C.c_void_p(blk.norm.bias.data_ptr()), C.c_void_p(blk.activation.weight.data_ptr()),
-                                                 C.c_void_p(blk.norm.running_mean.data_ptr()), C.c_void_p(blk.norm.running_var.data_ptr()),
+            norm, slope = _norm_of(blk.norm), getattr(blk.activation, "weight", None)
+            check(lib.tcvn_rows_bn_prelu_forward(C.c_void_p(z.data_ptr()), z.stride(0), rows, ch, _p(norm.weight if norm else None),
+                                                 _p(norm.bias if norm else None), _p(slope), _p(norm.running_mean if norm else None),
+                                                 _p(norm.running_var if norm else None),
                                                  C.c_void_p(y.data_ptr()), y.stride(0), C.c_void_p(stat.data_ptr()), int(training), p,
                                                  C.c_uint64(seed), C.c_uint32(0x4800 + i), _st()), "rows_bn_prelu_forward")
-            if training:
-                blk.norm.num_batches_tracked += 1
+            if training and norm is not None:
+                norm.num_batches_tracked += 1
             self.saved.append((x, z, stat, p, seed, 0x4800 + i))
             x = y
         return x
@@ -87,11 +98,12 @@ class FeatureMLP:
         for blk, (x, z, stat, p, seed, sid) in zip(reversed(self.blocks), reversed(self.saved)):
             rows, ch = z.shape
             dz = torch.empty_like(z)
+            norm, slope = _norm_of(blk.norm), getattr(blk.activation, "weight", None)
             check(lib.tcvn_rows_bn_prelu_backward(C.c_void_p(z.data_ptr()), z.stride(0), C.c_void_p(dy.data_ptr()), dy.stride(0), rows, ch,
-                                                  C.c_void_p(blk.norm.weight.data_ptr()), C.c_void_p(blk.norm.bias.data_ptr()),
-                                                  C.c_void_p(blk.activation.weight.data_ptr()), C.c_void_p(stat.data_ptr()),
-                                                  C.c_void_p(dz.data_ptr()), dz.stride(0), C.c_void_p(grads[blk.norm.weight].data_ptr()),
-                                                  C.c_void_p(grads[blk.norm.bias].data_ptr()), C.c_void_p(grads[blk.activation.weight].data_ptr()),
+                                                  _p(norm.weight if norm else None), _p(norm.bias if norm else None),
+                                                  _p(slope), C.c_void_p(stat.data_ptr()),
+                                                  C.c_void_p(dz.data_ptr()), dz.stride(0), _p(grads[norm.weight] if norm else None),
+                                                  _p(grads[norm.bias] if norm else None), _p(grads[slope] if slope is not None else None),
                                                   float(p), C.c_uint64(seed), C.c_uint32(sid), _st()), "rows_bn_prelu_backward")
             dx = torch.empty_like(x)
             gb = grads.get(blk.linear.bias) if blk.linear.bias is not None else None

@@ -61,8 +61,6 @@ class HipRuntime:
         self.seed = seed
         self.step = 0
         pe = network.prong_embedding
-        if not (options.linear_batch_norm and options.linear_prelu_activation):
-            raise NotImplementedError("the MI355X path implements LinearBlock as Linear-BatchNorm1d-PReLU (both option files)")
         self.smart_features = not bool(options.disable_smart_features)     # a8: ProngFeatureEmbedding MLP on the row kernels
         self.feature_mlp = None
         H, W = self.pixel_shape
@@ -74,7 +72,8 @@ class HipRuntime:
                                network.event_decoder.hidden_layer.out_features, dec.output_dim, dec.widths,
                                dec.output_layer.in_features, options.transformer_activation == "gelu",
                                bool(options.transformer_norm_first), float(options.dropout), float(options.loss_gamma),
-                               float(options.event_prong_loss_proportion))
+                               float(options.event_prong_loss_proportion), bool(options.linear_batch_norm),
+                               bool(options.linear_prelu_activation))
         self.anchor: Optional[Tensor] = None
         self.flat_param = self.flat_grad = self.flat_buf = None
         self._sig = None

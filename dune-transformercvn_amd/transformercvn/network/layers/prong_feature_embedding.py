@@ -1,6 +1,6 @@
 """LinearBlock / ProngFeatureEmbedding parameter holders (reference: transformercvn/network/layers/
-prong_feature_embedding.py:7-33, :36-78).  Linear -> BatchNorm1d -> PReLU -> Dropout; executed by the row kernels of
-csrc/rows.hip through the head engine."""
+prong_feature_embedding.py:7-33, :36-78).  Linear -> BatchNorm1d | Identity -> PReLU | ReLU -> Dropout (options.linear_batch_norm,
+options.linear_prelu_activation); executed by the row kernels of csrc/rows.hip through the head engine."""
 from __future__ import annotations
 
 import torch
@@ -17,7 +17,6 @@ class LinearBlock(nn.Module):
         self.norm = nn.BatchNorm1d(output_dim) if use_bn else nn.Identity()
         self.activation = nn.PReLU(output_dim) if options.linear_prelu_activation else nn.ReLU()
         self.dropout = nn.Dropout(options.dropout)
-        self._fused = isinstance(self.norm, nn.BatchNorm1d) and isinstance(self.activation, nn.PReLU)
 
     def forward(self, x: Tensor) -> Tensor:
         """Linear -> BatchNorm1d -> PReLU -> Dropout (reference :25-33).  Eager: the HIP row kernels (forward only, no autograd);
@@ -29,11 +28,10 @@ class LinearBlock(nn.Module):
     @torch.jit.unused
     def _hip_forward(self, x: Tensor) -> Tensor:
         from transformercvn.hip import rowops
-        if not self._fused:
-            raise NotImplementedError("the MI355X path implements LinearBlock as Linear-BatchNorm1d-PReLU (both option files)")
         z = rowops.linear(x, self.linear.weight, self.linear.bias)
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (self.training and self.dropout.p > 0) else 0
-        return rowops.bn_prelu(z, self.norm, self.activation.weight, self.training, self.dropout.p, seed, 0x5000)
+        # norm = BatchNorm1d | Identity (options.linear_batch_norm), activation = PReLU | ReLU (options.linear_prelu_activation)
+        return rowops.bn_prelu(z, self.norm, getattr(self.activation, "weight", None), self.training, self.dropout.p, seed, 0x5000)
 
 
 class ProngFeatureEmbedding(nn.Module):

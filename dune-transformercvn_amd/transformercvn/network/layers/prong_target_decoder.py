@@ -51,15 +51,19 @@ class ProngTargetDecoder(nn.Module):
         mods = list(self.hidden_layers)
         i = blk = 0
         while i < len(mods):
-            lin = mods[i]
-            if not (i + 2 < len(mods) + 0 and isinstance(mods[i + 1], nn.BatchNorm1d) and isinstance(mods[i + 2], nn.PReLU)):
-                raise NotImplementedError("the MI355X path implements the decoder blocks as Linear-BatchNorm1d-PReLU")
-            drop = mods[i + 3] if i + 3 < len(mods) and isinstance(mods[i + 3], nn.Dropout) else None
+            lin = mods[i]                     # create_linear_block: [Linear, BatchNorm1d?, PReLU | ReLU, Dropout?]
+            j = i + 1
+            norm = mods[j] if j < len(mods) and isinstance(mods[j], nn.BatchNorm1d) else None
+            j += norm is not None
+            act = mods[j]
+            j += 1
+            drop = mods[j] if j < len(mods) and isinstance(mods[j], nn.Dropout) else None
+            j += drop is not None
             h = rowops.linear(h, lin.weight, lin.bias)
             p = drop.p if (drop is not None and self.training) else 0.0
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
-            h = rowops.bn_prelu(h, mods[i + 1], mods[i + 2].weight, self.training, p, seed, 0x7000 + blk)
-            i += 4 if drop is not None else 3
+            h = rowops.bn_prelu(h, norm, getattr(act, "weight", None), self.training, p, seed, 0x7000 + blk)
+            i = j
             blk += 1
         h = rowops.linear(h, self.output_layer.weight, self.output_layer.bias)
         return h.reshape(T, B, self.output_dim)

@@ -139,6 +139,9 @@ typedef struct tcvn_head_cfg {
     int norm_first;
     int dropout_modules;                   /* 1 when options.dropout > 0 (shifts prong_decoder.hidden_layers idx)  */
     float dropout; float gamma; float event_weight;
+    int no_linear_bn;                      /* 1 = options.linear_batch_norm False: LinearBlock = Linear(bias)-act-Dropout, decoder blocks without
+                                              BatchNorm1d (prong_feature_embedding.py:11-16, encoder.py:13-14); 0 = the shipped option files   */
+    int linear_relu;                       /* 1 = options.linear_prelu_activation False: ReLU instead of PReLU (:18-21, :16-19), no slope slots  */
 } tcvn_head_cfg;
 
 typedef struct tcvn_head tcvn_head;
@@ -180,7 +183,9 @@ int tcvn_head_decode(tcvn_head* p, int batch, int max_prongs, const float* hidde
 /* Row operators behind the holder modules' own forward() (forward only, fp32):
  *   y = x W^T + b (torch.nn.Linear layout; bias may be NULL)                      -- layers/prong_decoder.py:15-16
  *   y = dropout(prelu(batchnorm1d(x)))  with batch statistics + running-stat update when train != 0, running statistics
- *   otherwise; save_mean_rstd: 2*channels floats of scratch                        -- layers/prong_feature_embedding.py:25-33 */
+ *   otherwise; save_mean_rstd: 2*channels floats of scratch                        -- layers/prong_feature_embedding.py:25-33
+ *   Option variants of the block (:11-21): gamma == beta == running_mean == running_var == NULL -> no BatchNorm1d (norm = Identity,
+ *   options.linear_batch_norm False); slope == NULL -> ReLU (options.linear_prelu_activation False).  Same rules in the backward. */
 int tcvn_linear_forward(const float* x, int64_t ldx, const float* weight, const float* bias, float* y, int64_t ldy, int rows,
                         int n_out, int n_in, void* stream);
 int tcvn_rows_bn_prelu_forward(const float* x, int64_t ldx, int rows, int channels, const float* gamma, const float* beta,

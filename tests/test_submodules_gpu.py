@@ -75,6 +75,30 @@ def test_linear_block_and_dense_net_forward_alone():
     assert float(np.abs(samp - g[pfx]).max()) / float(np.abs(g[pfx]).max()) < 1e-4
 
 
+@pytest.mark.parametrize("bn,prelu", [(False, True), (True, False), (False, False)])
+def test_linear_block_option_variants_forward_alone(bn, prelu):
+    """The holder modules' own forward for the LinearBlock option variants (reference layers/prong_feature_embedding.py:11-21,
+    layers/encoder.py:10-24: linear_batch_norm / linear_prelu_activation False) on the HIP row kernels against the same modules through
+    ATen on the CPU, eval mode."""
+    cfg = O.tutorial_config(densenet_structure=[1, 1], densenet_growth_rate=8, initial_pixel_dim=16, num_encoder_layers=1, pixel_embedding_dim=64,
+                            hidden_dim=64, num_prong_decoder_layers=3, dropout=0.1, pixel_noise_std=0.0, linear_batch_norm=bn,
+                            linear_prelu_activation=prelu)
+    model = build_trainer(cfg, O.fill_state(cfg, 5))
+    model.eval()
+    lb, dec = model.network.prong_embedding.combined_embedding, model.network.prong_decoder
+    assert isinstance(lb.norm, torch.nn.BatchNorm1d) == bn and isinstance(lb.activation, torch.nn.PReLU) == prelu
+    assert (lb.linear.bias is None) == bn
+    x = torch.randn(9, lb.linear.in_features, device="cuda")
+    h = torch.randn(3, 4, cfg.hidden_dim, device="cuda")
+    y, z = lb(x), dec(h)
+    import copy
+    lb_c, dec_c = copy.deepcopy(lb).cpu().eval(), copy.deepcopy(dec).cpu().eval()
+    with torch.no_grad():
+        ref_y = lb_c.dropout(lb_c.activation(lb_c.norm(lb_c.linear(x.cpu()))))
+        ref_z = dec_c.output_layer(dec_c.hidden_layers(h.cpu().reshape(12, -1))).reshape(3, 4, -1)
+    assert rel_err(y.cpu(), ref_y) < 1e-5 and rel_err(z.cpu(), ref_z) < 1e-5
+
+
 def test_stage_calls_on_cpu_fail_loudly():
     cfg, over, batch, g = load_case("small_b3")
     model = build_trainer(cfg, None, device=None)
