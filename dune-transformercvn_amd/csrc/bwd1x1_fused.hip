@@ -373,6 +373,7 @@ bool bwd1x1_fused_ok(const Bwd1x1Args& a) {
 }
 
 int bwd1x1_fused_nblk(const Bwd1x1Args& a) {
+    if (bwd1x1_wide_ok(a)) return bwd1x1_wide_nblk(a);       // 128 < cin <= 512: one workgroup per tile walks the column slices (bwd1x1_wide.hip)
     const int nn = cdiv(a.cin, 128);
     int cap = 512 / nn;                    // two resident workgroups per CU, shared by the nn column slices
     if (cap < 64) cap = 64;
@@ -384,6 +385,7 @@ int bwd1x1_fused_launch(const Bwd1x1Args& a, hipStream_t st) {
     if (a.M <= 0) return 0;
     if (!bwd1x1_fused_ok(a)) return -2;
     if (a.nblk != bwd1x1_fused_nblk(a)) { fprintf(stderr, "tcvn: bwd1x1_fused nblk mismatch\n"); return -3; }
+    if (bwd1x1_wide_ok(a)) return bwd1x1_wide_launch(a, st);
     static bool attr = false;
     if (!attr) {
         TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd1x1_fused_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -22,6 +22,8 @@ void tcvn::set_backward_overlap(int on) { g_backward_overlap = on; }
 namespace {
 constexpr float kEps = 1e-5f;
 constexpr long kSlabBytes = 48L << 20;      // per-workgroup partial weight gradients (<= 256 x 147 KB) and column sums
+constexpr long kSlab1GemmBytes = 64L << 20; // fused 1x1 backward: 256 workgroups x [128][512] fp32 (bwd1x1_wide.hip), bias column sums behind them
+constexpr long kSlab1Bytes = 68L << 20;
 constexpr long kSlabGemmBytes = 44L << 20;  // GEMM slabs; the tail [44 MB, 48 MB) holds the bias column-sum partials (<= 1024 x 512 floats)
 struct Bump {
     long off;
@@ -52,7 +54,7 @@ void DenseNetPlan::layout_bwd(int n, long start, long maxY, Layout& L) const {
     L.ey = b.take(maxY * esz);
     L.ey2 = b.take(maxY * esz);                    // second EY buffer: the weight-gradient stream may still read the previous one
     L.slab = b.take(kSlabBytes);
-    L.slab1 = cfg.mode == MODE_BF16 ? b.take(kSlabBytes) : -1;
+    L.slab1 = cfg.mode == MODE_BF16 ? b.take(kSlab1Bytes) : -1;
     L.pqY = b.take((long)mid * 8);
     L.du0 = b.take((long)n * Hc * Wc * cfg.init_ch * esz);
     L.pq0 = b.take((long)cfg.init_ch * 8);
@@ -81,8 +83,8 @@ bool DenseNetPlan::bwd1x1_fill(int bi, int l, long M, char* ws, const Layout& L,
     fa.Xin = ws + L.D[bi]; fa.ldx = bg.ld; fa.cin = ls.cin;
     fa.sc = tabs + tab_off(ls.n1); fa.sh = fa.sc + round_up(ls.n1.C, 8); fa.sl = data[ls.a1]; fa.Gout = ws + L.G[bi]; fa.ldg = bg.ld;
     fa.Wfrag = ws + L.wk + etf.off; fa.Kp = etf.Kp; fa.zeros = ws + L.zeros; fa.part = reinterpret_cast<double*>(ws + L.bpart);
-    fa.slab = reinterpret_cast<float*>(ws + L.slab1); fa.slab_bytes = kSlabGemmBytes; fa.ldc = wk_find(ls.w1, 0).Kp;
-    fa.tail = reinterpret_cast<float*>(ws + L.slab1 + kSlabGemmBytes);
+    fa.slab = reinterpret_cast<float*>(ws + L.slab1); fa.slab_bytes = kSlab1GemmBytes; fa.ldc = wk_find(ls.w1, 0).Kp;
+    fa.tail = reinterpret_cast<float*>(ws + L.slab1 + kSlab1GemmBytes);
     fa.nblk = bwd1x1_fused_nblk(fa);
     return bwd1x1_fused_ok(fa);
 }

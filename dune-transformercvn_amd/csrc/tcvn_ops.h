@@ -271,6 +271,9 @@ struct Bwd1x1Args {
 bool bwd1x1_fused_ok(const Bwd1x1Args& a);
 int bwd1x1_fused_nblk(const Bwd1x1Args& a);
 int bwd1x1_fused_launch(const Bwd1x1Args& a, hipStream_t st);
+bool bwd1x1_wide_ok(const Bwd1x1Args& a);       // bwd1x1_wide.hip: the same launch interface for 128 < cin <= 512 (called through bwd1x1_fused_*)
+int bwd1x1_wide_nblk(const Bwd1x1Args& a);
+int bwd1x1_wide_launch(const Bwd1x1Args& a, hipStream_t st);
 int bwd1x1_fused_reduce(const Bwd1x1Args& a, float* dWk, float* dbias, const SlabJob* extra, hipStream_t st, const BnBwdLinkArgs* link = nullptr);   // slab reductions into dWk [128][ldc], dbias [128]
                                                                                                   // (+ up to two more jobs in the same launch)
 
