@@ -1,10 +1,11 @@
-// Fused backward of a bottleneck 1x1 convolution for WIDE layers (128 < cin <= 512: dense blocks 2-5), round 5.
+// Fused backward of a bottleneck 1x1 convolution for WIDE layers (128 < cin <= 512, cin % 4 == 0: dense blocks 2-4), round 5.
+// A VALIDATED VARIANT, NOT THE PRODUCT PATH: it moves less data than k_bwd1x1_fused_bf16 and takes 20-30 % longer (numbers below).
 // Reference: autograd of Bottleneck.bottleneck_block = BN - PReLU - conv1 (layers/dense_net.py:18-27).  Same arithmetic, expression
 // by expression, as k_bwd1x1_fused_bf16 (bwd1x1_fused.hip); what differs is who walks the 128-column slices of the cin input channels:
 //
 //   k_bwd1x1_fused_bf16   one workgroup per (64-pixel tile, slice): gridDim.y slices, each workgroup re-reads DU / Y and rebuilds
 //                         EY = bf16(DU + PY*Y + QY) for its own slice -- two to four times per pixel in blocks 3-5 (306 MB of HBM / L2
-//                         traffic per average launch against 190 MB of strict bytes, and the EY arithmetic is 30 % of a tile's VALU work).
+//                         traffic per average launch against 190 MB of strict bytes).  Two workgroups per CU, 2 waves per SIMD.
 //   this kernel           one workgroup per TILE walks all NS slices: DU / Y are fetched and EY is formed ONCE per pixel; the NS
 //                         weight-gradient tiles (NS x 128 x 128 fp32 = NS x 64 registers per lane) stay in the accumulation registers
 //                         for the whole launch -- which is why a workgroup has a CU to itself (one wave per SIMD: 512 registers per lane).
@@ -15,6 +16,19 @@
 // loads, the G stores) in an order that is the SAME for every wave and every iteration -- lanes / waves without real work fetch the zero
 // page or store to a dump row -- so that the `s_waitcnt vmcnt(N)` in front of each consumer can carry a compile-time N (vmcnt retires in
 // issue order).  Barriers inside the pipeline are bare `s_barrier`s behind an LDS-only wait.
+//
+// Measured (MI355X, config-2 step, same box, tools/r05_ab2.sh + tools/per_block_trace.sh; profiles/r05_wide_variant_per_block.txt):
+// every launch it takes over is slower -- prong block 2 (two slices, 6 664 tiles) 235 us, block 3 two / three / four slices 70 / 101 / 130 us,
+// against 97 / 49 / 59 us AVERAGES of the per-slice kernel over the same launch groups (which include the event embedder's small launches):
+// 5.21 vs 4.46 ms per step in total, step 19.58 vs 19.18 ms.  4.6 us per (tile, slice) is ~10 000 cycles for ~1 400 instructions of one wave:
+// the memory schedule works (no vmcnt(0) drain, no scratch: tools/check_asm_loads.sh), but with ONE wave per SIMD every LDS round trip, every
+// dependent MFMA chain and every VALU dependency of the element-wise phases is exposed, and the phases of the four lock-stepped waves cannot
+// overlap MFMA with VALU work the way two independent workgroups per CU do.  The per-slice kernel's redundant DU / Y reads are L2 / MALL hits
+// that its second resident workgroup hides; the traffic this variant saves was not what bound the launch.
+//
+// Hand-issued loads and the compiler: a register the compiler believes loaded may be copied or spilled by it BEFORE the wait (seen twice
+// while this file was written: spills of the G-row registers into AGPRs right behind the load).  tools/check_asm_loads.sh replays the
+// generated ISA's main loop against the vmcnt queue and fails the build (Makefile: build/bwd1x1_wide.chk) on any such access.
 #include "tcvn_ops.h"
 #include "prof.h"
 
@@ -426,8 +440,10 @@ __global__ __launch_bounds__(256, 1) void k_bwd1x1_wide_bf16(const Bwd1x1Args g)
 }  // namespace
 
 bool bwd1x1_wide_ok(const Bwd1x1Args& a) {
-    static const bool off = TCVN_KNOB_SET("TCVN_NO_BWD1_WIDE");       // validation build: every width on k_bwd1x1_fused_bf16 (A/B and variant tests)
-    return !off && a.cin > 128 && a.cin <= 512 && (a.cin & 3) == 0 && a.Kp == 128 && a.ldc >= a.cin && a.M * 256L < (1L << 40);
+    // OPT-IN (validation build, TCVN_BWD1_WIDE=1): measured 20-30 % SLOWER than the per-slice kernel on every wide launch of the config-2
+    // step (header) -- the product library never selects it; tests/test_densenet_gpu.py keeps it correct
+    static const bool on = TCVN_KNOB_SET("TCVN_BWD1_WIDE");
+    return on && a.cin > 128 && a.cin <= 512 && (a.cin & 3) == 0 && a.Kp == 128 && a.ldc >= a.cin && a.M * 256L < (1L << 40);
 }
 int bwd1x1_wide_nblk(const Bwd1x1Args& a) {
     const long mt = (a.M + ROWS - 1) / ROWS;

@@ -546,10 +546,7 @@ result = dict(out=out, grads=grads)
     # Both sides on the validation build with the link kernels (TCVN_NO_LF): the three-kernel path implies the unfused forward, whose
     # statistics leave as partial rows -- against the product's fixed-point accumulators the BatchNorm tables would differ in their last
     # bits (1e-11 relative in the sums), which has nothing to do with the kernel under test.
-    # ... and with the per-slice kernel in the one wide layer (cin = 144; TCVN_NO_BWD1_WIDE): k_bwd1x1_wide_bf16 groups the statistics'
-    # partial sums by another tile -> workgroup map, which moves the tables below it by an fp32 ulp (its own test:
-    # test_wide_1x1_backward_matches_the_per_slice_kernel)
-    base = run_on_debug_build(body, dict(TCVN_NO_LF="1", TCVN_NO_BWD1_WIDE="1"))
+    base = run_on_debug_build(body, dict(TCVN_NO_LF="1"))
     ref = run_on_debug_build(body, dict(TCVN_NO_LF="1", TCVN_NO_BWD1_FUSE="1"))
     out, grads = base["out"], base["grads"]
     assert torch.equal(out, ref["out"])
@@ -714,7 +711,7 @@ result = dict(out=out, taps=taps, grads=grads)
 
 @pytest.mark.parametrize("init_ch,structure,hw", [(200, [4], (104, 72)),      # cin 200..296: two and three column slices, resident and streamed forward chunks
                                                   (100, [3], (104, 72)),      # cin 100, 132, 164: a last partial 8-channel chunk (cin % 8 == 4)
-                                                  (256, [6], (56, 40)),       # cin 256..416: two, three and (last layer) four column slices walked by one workgroup
+                                                  (256, [6], (56, 40)),       # cin 256..416: two, three and (last layer) four column slices
                                                   (250, [10], (56, 40))])     # cin 250..538 (cin % 8 == 2): up to four slices, K extents 256..544 (> 512: the forward falls back, backward five slices)
 def test_fused_1x1_kernels_on_odd_widths_and_partial_tiles(init_ch, structure, hw):
     """The fused 1x1 forward / backward kernels against the kernels they replace (TCVN_NO_BWD1_FUSE on the validation build disables both) on
@@ -777,8 +774,9 @@ result = dict(out=out, taps=taps, grads=grads)
                                                   (256, [6], (56, 40))])      # cin 256..416: the last layer four slices wide; 351 pixels per image (partial tiles)
 def test_wide_1x1_backward_matches_the_per_slice_kernel(init_ch, structure, hw):
     """Round 5: k_bwd1x1_wide_bf16<NS> (one workgroup per pixel tile walks the NS column slices of a layer with 128 < cin <= 512: DU / Y
-    fetched and EY formed once per pixel, every operand prefetched on a fixed schedule behind counted waits) against k_bwd1x1_fused_bf16
-    (one workgroup per (tile, slice); TCVN_NO_BWD1_WIDE on the validation build).  Element for element the same expressions with the same
+    fetched and EY formed once per pixel, every operand prefetched on a fixed schedule behind counted waits; opt-in on the validation build,
+    TCVN_BWD1_WIDE -- it measured slower than what it was to replace) against k_bwd1x1_fused_bf16 (one workgroup per
+    (tile, slice), the product path).  Element for element the same expressions with the same
     roundings; what differs is the grouping of the fp32 partial sums (statistics, weight-gradient tiles: another tile -> workgroup map)."""
     over = dict(densenet_structure=structure, initial_pixel_dim=init_ch, pixel_shape=hw, num_encoder_layers=2, dropout=0.1, pixel_noise_std=0.0)
     from variant_utils import run_on_debug_build
@@ -793,8 +791,8 @@ d_out = torch.randn(n_img, O.embed_dims(cfg)[0], generator=torch.Generator().man
 out, taps, grads = T._run_bf16(cfg, sd, batch, True, d_out)
 result = dict(out=out, grads=grads)
 """
-    base = run_on_debug_build(body, dict(TCVN_NO_LF="1"))
-    ref = run_on_debug_build(body, dict(TCVN_NO_LF="1", TCVN_NO_BWD1_WIDE="1"))
+    base = run_on_debug_build(body, dict(TCVN_NO_LF="1", TCVN_BWD1_WIDE="1"))
+    ref = run_on_debug_build(body, dict(TCVN_NO_LF="1"))
     assert torch.equal(base["out"], ref["out"])                      # the forward pass does not involve the kernel
     is_bias = lambda k: k.endswith(("conv0.bias", "conv1.bias", "conv2.bias", "conv.bias"))      # exact-zero gradients: rounding noise only
     errs = sorted(((((base["grads"][k] - ref["grads"][k]).norm() / ref["grads"][k].norm().clamp_min(1e-30)).item(), k)
