@@ -195,26 +195,31 @@ __device__ __forceinline__ void slab_reduce_body(const SlabJob& j, float (*red)[
     const int s0 = blockIdx.y * j.per_y, s1 = min(j.nslab, s0 + j.per_y);
     const float* __restrict__ slab = j.slab;
     if (j.v4) {
-        // 16 B per lane: a block covers 256 columns.  (Round 4: the scalar version moved the 37.7 MB slabs of a 3x3 weight gradient at
-        // 0.7 TB/s -- 56 us per launch in the kernel trace, half the time of the weight-gradient kernel it follows.)
-        const long i = ((long)blockIdx.x * 64 + cx) * 4;
-        if ((long)blockIdx.x * 256 >= j.count) return;
+        // 16 B per lane: a block covers 128 columns with eight slab lanes, eight loads in flight per thread.  (Round 4: the scalar version
+        // moved the 37.7 MB slabs of a 3x3 weight gradient at 0.7 TB/s.  Round 5: with the slabs split over up to 16 y-slices the launch
+        // spent its time in the fp32 atomics that merge the slices -- 557 K of them per dense layer; one y-slice per job (every launch of
+        // the DenseNet plan: <= 512 slabs) adds into dst directly, in a fixed order: 19.40 -> 19.17 ms per step, tools/r05_ab2.sh.)
+        const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        const long i = ((long)blockIdx.x * 32 + cl) * 4;
+        if ((long)blockIdx.x * 128 >= j.count) return;
         typedef __attribute__((ext_vector_type(4))) float f4;
-        f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        f4 acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
         if (i < j.count) {
-            int k = s0 + sg;
-            for (; k + 12 < s1; k += 16) {
-                const f4 v0 = *reinterpret_cast<const f4*>(slab + (long)k * j.stride + i), v1 = *reinterpret_cast<const f4*>(slab + (long)(k + 4) * j.stride + i);
-                const f4 v2 = *reinterpret_cast<const f4*>(slab + (long)(k + 8) * j.stride + i), v3 = *reinterpret_cast<const f4*>(slab + (long)(k + 12) * j.stride + i);
-                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            const float* base = slab + i;
+            int k = s0 + sl;
+            for (; k + 56 < s1; k += 64) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += *reinterpret_cast<const f4*>(base + (long)(k + 8 * q) * j.stride);
             }
-            for (; k < s1; k += 4) a0 += *reinterpret_cast<const f4*>(slab + (long)k * j.stride + i);
+            for (; k < s1; k += 8) acc[0] += *reinterpret_cast<const f4*>(base + (long)k * j.stride);
         }
-        *reinterpret_cast<f4*>(&red[sg][cx * 4]) = (a0 + a1) + (a2 + a3);
+        f4 (*red4)[32] = reinterpret_cast<f4 (*)[32]>(&red[0][0]);         // [8][32] f4 = the 4 x 256 floats of `red`
+        red4[sl][cl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         __syncthreads();
-        if (sg == 0 && i < j.count) {
-            const f4 v = (*reinterpret_cast<const f4*>(&red[0][cx * 4]) + *reinterpret_cast<const f4*>(&red[1][cx * 4])) +
-                         (*reinterpret_cast<const f4*>(&red[2][cx * 4]) + *reinterpret_cast<const f4*>(&red[3][cx * 4]));
+        if (sl == 0 && i < j.count) {
+            const f4 v = ((red4[0][cl] + red4[1][cl]) + (red4[2][cl] + red4[3][cl])) + ((red4[4][cl] + red4[5][cl]) + (red4[6][cl] + red4[7][cl]));
             if (j.ny == 1) { f4* d = reinterpret_cast<f4*>(j.dst + i); *d = *d + v; }
             else { atomicAdd(j.dst + i, v.x); atomicAdd(j.dst + i + 1, v.y); atomicAdd(j.dst + i + 2, v.z); atomicAdd(j.dst + i + 3, v.w); }
         }
@@ -320,7 +325,8 @@ SlabJob slab_job(const float* slab, int nslab, long count, float* dst, long stri
     SlabJob j{slab, dst, nslab, count, stride > 0 ? stride : count, 1, 1, 0};
     if (count <= 0 || nslab <= 0) { j.count = 0; return j; }
     j.v4 = (count % 4 == 0 && j.stride % 4 == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && count >= 1024) ? 1 : 0;
-    int ny = cdiv(nslab, j.v4 ? 32 : 64);            // 16-B lanes: a quarter of the workgroups per slab row -> split the slabs finer
+    static const int per_knob = TCVN_KNOB_INT("TCVN_SLAB_PER");     // validation build: slabs per y-slice of the 16-B path (A/B)
+    int ny = cdiv(nslab, j.v4 ? (per_knob > 0 ? per_knob : 512) : 64);           // 16-B path: one y-slice up to 512 slabs (no atomics; see slab_reduce_body)
     if (ny > 16) ny = 16;
     j.ny = ny; j.per_y = cdiv(nslab, ny);
     return j;
@@ -332,7 +338,7 @@ int slab_reduce4(const SlabJob* jobs, int n, hipStream_t st) {
     for (int i = 0; i < n && i < 4; ++i) {
         if (jobs[i].count <= 0) continue;
         j[nz++] = jobs[i];
-        const long g = cdiv(jobs[i].count, jobs[i].v4 ? 256 : 64);
+        const long g = cdiv(jobs[i].count, jobs[i].v4 ? 128 : 64);
         gmax = g > gmax ? g : gmax; nymax = jobs[i].ny > nymax ? jobs[i].ny : nymax;
     }
     if (nz == 0) return 0;
@@ -346,7 +352,7 @@ int slab_reduce4_link(const SlabJob* jobs, int n, const BnBwdLinkArgs& link, hip
     for (int i = 0; i < n && i < 4; ++i) {
         if (jobs[i].count <= 0) continue;
         j[nz++] = jobs[i];
-        const long g = cdiv(jobs[i].count, jobs[i].v4 ? 256 : 64);
+        const long g = cdiv(jobs[i].count, jobs[i].v4 ? 128 : 64);
         gmax = g > gmax ? g : gmax; nymax = jobs[i].ny > nymax ? jobs[i].ny : nymax;
     }
     hipLaunchKernelGGL(k_slab_reduce_link, dim3((unsigned)gmax, nymax, nz + 1), dim3(256), 0, st, j[0], j[1], j[2], j[3], nz, link);

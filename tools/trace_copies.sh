@@ -2,7 +2,7 @@
 # What issues the ~300 small rocclr copyBuffer launches per step?  One short bench run under rocprofv3 with the kernel, HIP-runtime and
 # memory-copy traces; prints the copies' direction/size histogram and the kernels that surround the copy kernels.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r03c
+OUT=$ROOT/gpurun_out/${1:-r05c}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace -d $OUT/tr -o tr --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32 --no-sdxl --no-batch8 --no-profile > $OUT/bench.json 2> $OUT/bench.err
