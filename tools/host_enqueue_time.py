@@ -7,11 +7,12 @@ from transformercvn.options import Options
 from transformercvn.network.trainers.neutrino_full_dense_trainer import NeutrinoFullDenseTrainer
 dev = torch.device("cuda:0")
 opt = Options.load(os.path.join(bench.PKG, "option_files", "tutorial_densenet_synthetic.json"))
-opt.batch_size, opt.num_gpu, opt.hip_precision = 32, 1, "bf16"
+BN = int(os.environ.get("TIME_BATCH", "32"))
+opt.batch_size, opt.num_gpu, opt.hip_precision = BN, 1, "bf16"
 opt.training_file = "synthetic:64:8"
 model = NeutrinoFullDenseTrainer(opt).to(dev); model.train()
 rt = model.network.hip_runtime(); rt.ensure_bound()
-batch = bench.make_batch(32, 8, 1234, dev)
+batch = bench.make_batch(BN, 8, 1234, dev)
 def step():
     rt.zero_grad(); loss = model.training_step(batch, 0); loss.backward(); return loss
 for _ in range(3): step()
