@@ -54,6 +54,53 @@ __device__ __forceinline__ void gemm128(const float* xin, int ldx, int g, const 
         }
     }
 }
+// The same product on the matrix pipe (round 5): OUT[r][c] = sum_k A[r][k] * Wl[c][k] for the wave's 32 output columns and MT 16-row tiles of
+// token rows, `v_mfma_f32_16x16x4_f32` (exact fp32 products, fp32 accumulation: a k-ordered fmaf chain in another k order than gemm128's).
+// Lane (r = lane & 15, q = lane >> 4) holds A[r][k] and B[k][r] for ONE k per instruction; it reads its operands as float4 at
+// k = 16 kk + 4 q .. + 3 and feeds component j to the j-th instruction of the group -- any assignment of k values to (instruction, q) works
+// as long as A and B agree.  A's pitch must not be a multiple of 64 floats (XLD / QLD: the 16 rows of a read then fall on distinct
+// banks; at pitch 128 they are a 16-way conflict).  Rows beyond the padded sequence read whatever LDS holds (or zero past the
+// allocation): their results are never used.
+constexpr int XLD = 132;
+template <int MT>
+__device__ __forceinline__ void gemm128_mfma(const float* A, int lda, const float* Wl, f32x4 (&acc)[MT][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ap = A + r * lda + 4 * q;
+    const float* bp = Wl + (wave * 32 + r) * WLD + 4 * q;
+#pragma unroll 2
+    for (int kk = 0; kk < D / 16; ++kk) {
+        f32x4 av[MT], bv[2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const f32x4*>(ap + m * 16 * lda + 16 * kk);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bv[t] = *reinterpret_cast<const f32x4*>(bp + t * 16 * WLD + 16 * kk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][j], bv[t][j], acc[m][t], 0, 0, 0);
+    }
+}
+// visit the wave's results: f(row, tile-of-columns t, column, value) for every row < rows  (D layout: column = lane & 15, row = 4 (lane >> 4) + register)
+template <int MT, typename F>
+__device__ __forceinline__ void mfma_results(const f32x4 (&acc)[MT][2], int rows, F f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = m * 16 + 4 * (lane >> 4) + j;
+                if (row < rows) f(row, t, wave * 32 + t * 16 + (lane & 15), acc[m][t][j]);
+            }
+}
 // transposed product over one 64-row half block: acc[i] += sum_{n < 64} dy[g + 2 i][n0 + n] * Wl[n][k]
 template <int NR>
 __device__ __forceinline__ void gemm_t64(const float* dy, int ldy, int n0, int g, const float* Wl, int k, float (&acc)[NR]) {
@@ -84,8 +131,8 @@ __device__ __forceinline__ void fill_mask(float* mask, int S, int B, int b, floa
     }
 }
 
-// rows of `y` (LDS, stride D) -> LayerNorm: xhat and rstd to global, gamma * xhat + beta to LDS `out` and global `outg`
-__device__ __forceinline__ void ln_rows(const float* y, int S, int B, int b, const float* gamma, const float* beta, float eps, float* out,
+// rows of `y` (LDS, stride D) -> LayerNorm: xhat and rstd to global, gamma * xhat + beta to LDS `out` (stride ldo) and global `outg`
+__device__ __forceinline__ void ln_rows(const float* y, int S, int B, int b, const float* gamma, const float* beta, float eps, float* out, int ldo,
                                         float* outg, float* xhg, float* rstdg) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float g0 = gamma[lane], g1 = gamma[lane + 64], b0 = beta[lane], b1 = beta[lane + 64];
@@ -98,7 +145,7 @@ __device__ __forceinline__ void ln_rows(const float* y, int S, int B, int b, con
         const long t = (long)s * B + b;
         const float h0 = c0 * rstd, h1 = c1 * rstd;
         const float o0 = h0 * g0 + b0, o1 = h1 * g1 + b1;
-        out[s * D + lane] = o0; out[s * D + lane + 64] = o1;
+        out[s * ldo + lane] = o0; out[s * ldo + lane + 64] = o1;
         if (outg) { outg[t * D + lane] = o0; outg[t * D + lane + 64] = o1; }
         if (xhg) { xhg[t * D + lane] = h0; xhg[t * D + lane + 64] = h1; }
         if (rstdg && lane == 0) rstdg[t] = rstd;
@@ -114,26 +161,27 @@ __global__ __launch_bounds__(256, 1) void k_encoder_fwd(const EncFusedArgs a) {
     constexpr int SP = 2 * NR, H = D / HD;          // padded rows
     const int S = a.S, B = a.B, b = blockIdx.x, tid = threadIdx.x;
     float* Wl = lds;                         // [128][WLD]
-    float* xin = Wl + D * WLD;               // [SP][D]   layer input
-    float* qkv = xin + SP * D;               // [SP][QLD] q | k | v, later the pre-LayerNorm sums ([SP][D])
-    float* ctx = qkv + SP * QLD;             // [SP][D]
-    float* x1 = ctx + SP * D;                // [SP][D]
-    float* hb = x1 + SP * D;                 // [SP][D]   FFN activation
-    float* mask = hb + SP * D;               // [SP][D]   dropout keep-scales of the site being applied
+    float* xin = Wl + D * WLD;               // [SP][XLD] layer input               (xin, ctx, x1, hb are MFMA A operands: pitch XLD)
+    float* qkv = xin + SP * XLD;             // [SP][QLD] q | k | v, later the pre-LayerNorm sums ([SP][D])
+    float* ctx = qkv + SP * QLD;             // [SP][XLD]
+    float* x1 = ctx + SP * XLD;              // [SP][XLD]
+    float* hb = x1 + SP * XLD;               // [SP][XLD] FFN activation
+    float* mask = hb + SP * XLD;             // [SP][D]   dropout keep-scales of the site being applied
     float* sc = x1;                          // [H][S][S + 1] attention probabilities: x1 | hb are dead while attention runs (their
                                              // padding rows may keep scores afterwards: rows >= S never reach a real row)
     int* valid = reinterpret_cast<int*>(mask + SP * D);
     static_assert(H * SMAX * (SMAX + 1) <= 2 * 2 * 11 * D, "score buffer must fit x1 | hb at the largest bucket");
-    const int c = tid & 127, g = tid >> 7;
+    constexpr int MT = SP > 16 ? 2 : 1;      // 16-row MFMA tiles of token rows
+    const int bcol = (tid >> 6) * 32 + (tid & 15);           // this lane's output column in column tile t is bcol + 16 t
     const float dp = a.drop_p;
     for (int i = tid; i < SP * D; i += 256) {
         const int s = i >> 7, d = i & 127;
-        xin[i] = s < S ? a.X0[((long)s * B + b) * D + d] : 0.f;
-        ctx[i] = 0.f; x1[i] = 0.f; hb[i] = 0.f; mask[i] = 1.f;
+        xin[s * XLD + d] = s < S ? a.X0[((long)s * B + b) * D + d] : 0.f;
+        ctx[s * XLD + d] = 0.f; x1[s * XLD + d] = 0.f; hb[s * XLD + d] = 0.f; mask[i] = 1.f;
     }
     if (tid < SMAX) valid[tid] = tid < S ? a.tok_row[b * S + tid] >= 0 : 0;
     f32x4 wreg[16];
-    float acc[NR];
+    f32x4 acc[MT][2];
     w_issue<16>(a.w[0].win, wreg);
 #pragma unroll 1
     for (int l = 0; l < a.L; ++l) {
@@ -147,15 +195,13 @@ __global__ __launch_bounds__(256, 1) void k_encoder_fwd(const EncFusedArgs a) {
             w_commit<16>(Wl, wreg);
             __syncthreads();
             w_issue<16>(ch < 2 ? W.win + (ch + 1) * D * D : W.wo, wreg);
-            gemm128<NR>(xin, D, g, Wl, c, acc);
-            const float bias = W.bin[ch * D + c];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int s = g + 2 * i;
-                const float v = acc[i] + bias;
+            gemm128_mfma<MT>(xin, XLD, Wl, acc);
+            const float bias[2] = {W.bin[ch * D + bcol], W.bin[ch * D + bcol + 16]};
+            mfma_results<MT>(acc, SP, [&](int s, int t, int c, float v0) {
+                const float v = v0 + bias[t];
                 qkv[s * QLD + ch * D + c] = v;
                 if (s < S && a.save) O.qkv[((long)s * B + b) * 3 * D + ch * D + c] = v;
-            }
+            });
         }
         __syncthreads();
         // ---- attention: thread (h, s); probabilities through LDS ----------------------------------------------------------
@@ -197,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void k_encoder_fwd(const EncFusedArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < HD; ++e) {
-                ctx[s * D + h * HD + e] = cx[e];
+                ctx[s * XLD + h * HD + e] = cx[e];
                 if (a.save) O.ctx[((long)s * B + b) * D + h * HD + e] = cx[e];
             }
         }
@@ -207,60 +253,52 @@ __global__ __launch_bounds__(256, 1) void k_encoder_fwd(const EncFusedArgs a) {
         w_commit<16>(Wl, wreg);
         __syncthreads();
         w_issue<16>(W.w1, wreg);
-        gemm128<NR>(ctx, D, g, Wl, c, acc);
+        gemm128_mfma<MT>(ctx, XLD, Wl, acc);
         {
-            const float bias = W.bo[c];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int s = g + 2 * i;
-                const float r = (acc[i] + bias) * mask[s * D + c];
-                qkv[s * D + c] = xin[s * D + c] + r;                 // q|k|v are dead: reuse as the [SP][D] sum buffer
-            }
+            const float bias[2] = {W.bo[bcol], W.bo[bcol + 16]};
+            mfma_results<MT>(acc, SP, [&](int s, int t, int c, float v0) {
+                const float r = (v0 + bias[t]) * mask[s * D + c];
+                qkv[s * D + c] = xin[s * XLD + c] + r;               // q|k|v are dead: reuse as the [SP][D] sum buffer
+            });
         }
         __syncthreads();
-        ln_rows(qkv, S, B, b, W.g1, W.be1, a.eps, x1, a.save ? O.x1 : nullptr, a.save ? O.xh1 : nullptr, a.save ? O.rstd1 : nullptr);
+        ln_rows(qkv, S, B, b, W.g1, W.be1, a.eps, x1, XLD, a.save ? O.x1 : nullptr, a.save ? O.xh1 : nullptr, a.save ? O.rstd1 : nullptr);
         if (dp > 0.f) fill_mask(mask, S, B, b, dp, a.seed, sid + 2);
         // ---- FFN -----------------------------------------------------------------------------------------------------------
         __syncthreads();
         w_commit<16>(Wl, wreg);
         __syncthreads();
         w_issue<16>(W.w2, wreg);
-        gemm128<NR>(x1, D, g, Wl, c, acc);
+        gemm128_mfma<MT>(x1, XLD, Wl, acc);
         {
-            const float bias = W.b1[c];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int s = g + 2 * i;
-                const float x = acc[i] + bias;
+            const float bias[2] = {W.b1[bcol], W.b1[bcol + 16]};
+            mfma_results<MT>(acc, S, [&](int s, int t, int c, float v0) {
+                const float x = v0 + bias[t];
                 const float y = (a.gelu ? 0.5f * x * (1.f + erff(x * kInvSqrt2)) : fmaxf(x, 0.f)) * mask[s * D + c];
-                if (s < S) {
-                    hb[s * D + c] = y;
-                    if (a.save) { const long t = (long)s * B + b; O.hpre[t * D + c] = x; O.hact[t * D + c] = y; }
-                }
-            }
+                hb[s * XLD + c] = y;
+                if (a.save) { const long tt = (long)s * B + b; O.hpre[tt * D + c] = x; O.hact[tt * D + c] = y; }
+            });
         }
         __syncthreads();
         if (dp > 0.f) fill_mask(mask, S, B, b, dp, a.seed, sid + 3);
         w_commit<16>(Wl, wreg);
         __syncthreads();
         if (l + 1 < a.L) w_issue<16>(a.w[l + 1].win, wreg);
-        gemm128<NR>(hb, D, g, Wl, c, acc);
+        gemm128_mfma<MT>(hb, XLD, Wl, acc);
         {
-            const float bias = W.b2[c];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int s = g + 2 * i;
-                const float r = (acc[i] + bias) * mask[s * D + c];
-                qkv[s * D + c] = x1[s * D + c] + r;
-            }
+            const float bias[2] = {W.b2[bcol], W.b2[bcol + 16]};
+            mfma_results<MT>(acc, SP, [&](int s, int t, int c, float v0) {
+                const float r = (v0 + bias[t]) * mask[s * D + c];
+                qkv[s * D + c] = x1[s * XLD + c] + r;
+            });
         }
         __syncthreads();
-        ln_rows(qkv, S, B, b, W.g2, W.be2, a.eps, xin, O.xnext, a.save ? O.xh2 : nullptr, a.save ? O.rstd2 : nullptr);
+        ln_rows(qkv, S, B, b, W.g2, W.be2, a.eps, xin, XLD, O.xnext, a.save ? O.xh2 : nullptr, a.save ? O.rstd2 : nullptr);
     }
     __syncthreads();
     for (int i = tid; i < S * D; i += 256) {                              // hidden * sequence_mask (:73)
         const int s = i >> 7, d = i & 127;
-        a.HID[((long)s * B + b) * D + d] = valid[s] ? xin[i] : 0.f;
+        a.HID[((long)s * B + b) * D + d] = valid[s] ? xin[s * XLD + d] : 0.f;
     }
 }
 
@@ -528,11 +566,19 @@ __global__ __launch_bounds__(256) void k_encoder_wgrad(const EncWgradArgs a) {
 
 // rows per thread for a sequence of S tokens: the smallest instantiated bucket
 int rows_bucket(int S) { const int r = (S + 1) / 2; return r <= 3 ? 3 : r <= 5 ? 5 : r <= 8 ? 8 : 11; }
+// dynamic LDS of the forward kernel.  The MFMA products read 16 (32 for the largest bucket) rows of their A operand whatever the padded
+// sequence length: the last operand buffer (hb) is followed by the mask and the validity words; pad so that those reads stay inside.
+size_t fwd_smem(int SP) {
+    const int MT = SP > 16 ? 2 : 1;
+    long over = (long)16 * MT * XLD - ((long)SP * XLD + (long)SP * D + SMAX);
+    if (over < 0) over = 0;
+    return ((size_t)D * WLD + (size_t)SP * (D + 4 * XLD + QLD) + (size_t)over) * 4 + SMAX * 4 + 64;
+}
 
 template <int HD, int NR>
 int launch_fwd(const EncFusedArgs& a, hipStream_t st) {
     constexpr int SP = 2 * NR, H = D / HD;
-    const size_t smem = ((size_t)D * WLD + (size_t)SP * (5 * D + QLD)) * 4 + SMAX * 4 + 64;
+    const size_t smem = fwd_smem(SP);
     if (H * a.S * (a.S + 1) > 2 * SP * D) return -2;
     static bool attr[16] = {};                  // per device: the attribute belongs to the device's copy of the function
     int dev = 0;
@@ -572,7 +618,7 @@ bool encoder_fused_ok(int S, int Dm, int H, int L, int norm_first) {
     const int SP = 2 * rows_bucket(S);
     if ((long)H * S * (S + 1) > 2L * SP * D) return false;                          // score rows alias the token buffers (forward)
     if (2L * H * SMAX * (SMAX + 1) > (long)HR * WLD) return false;                  // dS / dropped-P exchange aliases the weight image (backward)
-    const size_t smem_f = ((size_t)D * WLD + (size_t)SP * (5 * D + QLD)) * 4 + SMAX * 4 + 64;
+    const size_t smem_f = fwd_smem(SP);
     const size_t smem_b = ((size_t)HR * WLD + (size_t)SP * (4 * D + 2 * QLD)) * 4 + 64;
     return smem_f <= 160 * 1024 && smem_b <= 160 * 1024;
 }
