@@ -5,9 +5,9 @@
 //
 // An event's (1 + P) <= 22 tokens x 128 features live in LDS for the whole stack; every weight block is streamed from L2
 // through registers into a padded LDS image (prefetched one block ahead, under the previous block's arithmetic and the
-// attention / LayerNorm phases) and consumed by exact fp32 FMA chains.  Thread (c, g): output column c = tid & 127, token rows
-// g, g+2, ... ; the row count per thread NR is a template parameter (rows beyond the sequence are zero padding in LDS), so the
-// inner loops carry no predicates.  Dropout masks are the same stateless draws as in encoder.hip (stream ids 0x6000 + 8 l +
+// attention / LayerNorm phases) and consumed by fp32 MFMAs (v_mfma_f32_16x16x4_f32: exact fp32 products and accumulation; round 5 --
+// before that fp32 FMA chains, thread (c, g) = output column c, token rows g, g+2, ...).  The padded row count SP = 2 NR is a template
+// parameter (rows beyond the sequence are zero padding in LDS); a wave owns 32 output columns x one or two 16-row tiles.  Dropout masks are the same stateless draws as in encoder.hip (stream ids 0x6000 + 8 l +
 // {0,1,2,3}, element index of the sequence-major row), evaluated by rolled loops into an LDS mask buffer.
 // Everything the backward reads is written to the workspace buffers the unfused kernels of encoder.hip fill, so either forward
 // can feed either backward.
@@ -36,25 +36,7 @@ __device__ __forceinline__ void w_commit(float* Wl, const f32x4 (&reg)[NV]) {
         *reinterpret_cast<f32x4*>(Wl + (idx >> 5) * WLD + (idx & 31) * 4) = reg[i];
     }
 }
-// forward product: acc[i] = sum_k xin[g + 2 i][k] * Wl[c][k]
-template <int NR>
-__device__ __forceinline__ void gemm128(const float* xin, int ldx, int g, const float* Wl, int c, float (&acc)[NR]) {
-#pragma unroll
-    for (int i = 0; i < NR; ++i) acc[i] = 0.f;
-    const float* wrow = Wl + c * WLD;
-    const float* xr = xin + g * ldx;
-#pragma unroll 2
-    for (int k = 0; k < D; k += 4) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + k);
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(xr + 2 * i * ldx + k);
-            acc[i] = fmaf(x.x, w.x, acc[i]); acc[i] = fmaf(x.y, w.y, acc[i]);
-            acc[i] = fmaf(x.z, w.z, acc[i]); acc[i] = fmaf(x.w, w.w, acc[i]);
-        }
-    }
-}
-// The same product on the matrix pipe (round 5): OUT[r][c] = sum_k A[r][k] * Wl[c][k] for the wave's 32 output columns and MT 16-row tiles of
+// Forward product on the matrix pipe (round 5; rounds 2-4: fp32 FMA chains of a thread per (column, row pair)): OUT[r][c] = sum_k A[r][k] * Wl[c][k] for the wave's 32 output columns and MT 16-row tiles of
 // token rows, `v_mfma_f32_16x16x4_f32` (exact fp32 products, fp32 accumulation: a k-ordered fmaf chain in another k order than gemm128's).
 // Lane (r = lane & 15, q = lane >> 4) holds A[r][k] and B[k][r] for ONE k per instruction; it reads its operands as float4 at
 // k = 16 kk + 4 q .. + 3 and feeds component j to the j-th instruction of the group -- any assignment of k values to (instruction, q) works
@@ -101,20 +83,38 @@ __device__ __forceinline__ void mfma_results(const f32x4 (&acc)[MT][2], int rows
                 if (row < rows) f(row, t, wave * 32 + t * 16 + (lane & 15), acc[m][t][j]);
             }
 }
-// transposed product over one 64-row half block: acc[i] += sum_{n < 64} dy[g + 2 i][n0 + n] * Wl[n][k]
-template <int NR>
-__device__ __forceinline__ void gemm_t64(const float* dy, int ldy, int n0, int g, const float* Wl, int k, float (&acc)[NR]) {
-    const float* yr = dy + g * ldy + n0;
-#pragma unroll 2
-    for (int n = 0; n < HR; n += 4) {
-        const float w0 = Wl[(n + 0) * WLD + k], w1 = Wl[(n + 1) * WLD + k], w2 = Wl[(n + 2) * WLD + k], w3 = Wl[(n + 3) * WLD + k];
+// transposed product over one 64-row half block of the weight image, on the matrix pipe: acc[r][c] += sum_{n < 64} dy[r][n0 + n] * Wl[n][c] for the wave's 32 columns c (A = dy: float4 per lane along n,
+// pitch not a multiple of 64 floats; B = four b32 reads down the rows of the weight image: bank (16 q + column) mod 64, conflict-free)
+template <int MT>
+__device__ __forceinline__ void gemm_t64_mfma(const float* dy, int ldy, int n0, const float* Wl, f32x4 (&acc)[MT][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const float* ap = dy + r * ldy + n0 + 4 * q;
+    const float* bp = Wl + 4 * q * WLD + wave * 32 + r;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const f32x4 y = *reinterpret_cast<const f32x4*>(yr + 2 * i * ldy + n);
-            acc[i] = fmaf(y.x, w0, acc[i]); acc[i] = fmaf(y.y, w1, acc[i]);
-            acc[i] = fmaf(y.z, w2, acc[i]); acc[i] = fmaf(y.w, w3, acc[i]);
-        }
+    for (int kk = 0; kk < HR / 16; ++kk) {
+        f32x4 av[MT];
+        float bv[2][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const f32x4*>(ap + m * 16 * ldy + 16 * kk);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[t][j] = bp[(16 * kk + j) * WLD + t * 16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][j], bv[t][j], acc[m][t], 0, 0, 0);
     }
+}
+template <int MT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][2]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 // mask[s][c] = dropout keep-scale of element (t = s*B + b, c) of a [T][D] site
 __device__ __forceinline__ void fill_mask(float* mask, int S, int B, int b, float dp, uint64_t seed, uint32_t sid) {
@@ -307,24 +307,24 @@ __global__ __launch_bounds__(256, 1) void k_encoder_fwd(const EncFusedArgs a) {
 // =====================================================================================================================
 // LayerNorm backward of the rows in `dy` (LDS): ds -> `res` (LDS, the residual branch) and mask * ds -> `br` (LDS) + `brg` (global).
 // Per-event column sums of dy*xhat and dy go to lnp[0][c], lnp[1][c] (global, this event's slice) via `red` (LDS, 4 x 256 floats).
-__device__ __forceinline__ void ln_bwd_rows(const float* dy, int S, int B, int b, const float* gamma, const float* xhg, const float* rstdg,
-                                            float* res, float* br, float* brg, const float* mask, float* red, float* lnp) {
+__device__ __forceinline__ void ln_bwd_rows(const float* dy, int ldy, int S, int B, int b, const float* gamma, const float* xhg, const float* rstdg,
+                                            float* res, int ldr, float* br, int ldb, float* brg, const float* mask, float* red, float* lnp) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float ga0 = 0.f, ga1 = 0.f, be0 = 0.f, be1 = 0.f;
     const float g0 = gamma[lane], g1 = gamma[lane + 64];
 #pragma unroll 1
     for (int s = wave; s < S; s += 4) {
         const long t = (long)s * B + b;
-        const float y0 = dy[s * D + lane], y1 = dy[s * D + lane + 64];
+        const float y0 = dy[s * ldy + lane], y1 = dy[s * ldy + lane + 64];
         const float h0 = xhg[t * D + lane], h1 = xhg[t * D + lane + 64];
         ga0 = fmaf(y0, h0, ga0); ga1 = fmaf(y1, h1, ga1); be0 += y0; be1 += y1;
         const float a0 = y0 * g0, a1 = y1 * g1;
         const float s1 = wave_sum(a0 + a1) / D, s2 = wave_sum(a0 * h0 + a1 * h1) / D;
         const float rstd = rstdg[t];
         const float d0 = rstd * (a0 - s1 - h0 * s2), d1 = rstd * (a1 - s1 - h1 * s2);
-        res[s * D + lane] = d0; res[s * D + lane + 64] = d1;
+        res[s * ldr + lane] = d0; res[s * ldr + lane + 64] = d1;
         const float r0 = d0 * mask[s * D + lane], r1 = d1 * mask[s * D + lane + 64];
-        br[s * D + lane] = r0; br[s * D + lane + 64] = r1;
+        br[s * ldb + lane] = r0; br[s * ldb + lane + 64] = r1;
         brg[t * D + lane] = r0; brg[t * D + lane + 64] = r1;
     }
     red[wave * 256 + lane] = ga0; red[wave * 256 + 64 + lane] = ga1; red[wave * 256 + 128 + lane] = be0; red[wave * 256 + 192 + lane] = be1;
@@ -339,22 +339,22 @@ __global__ __launch_bounds__(256, 1) void k_encoder_bwd(const EncFusedBwdArgs a)
     constexpr int SP = 2 * NR, H = D / HD;
     const int S = a.S, B = a.B, b = blockIdx.x, tid = threadIdx.x;
     float* Wl = lds;                         // [64][WLD]; doubles as the dS / Pd exchange and the LayerNorm reduction scratch
-    float* bA = Wl + HR * WLD;               // [SP][D]
-    float* bB = bA + SP * D;                 // [SP][D]
-    float* bC = bB + SP * D;                 // [SP][D]
-    float* bQ = bC + SP * D;                 // [SP][QLD] saved q | k | v
+    float* bA = Wl + HR * WLD;               // [SP][XLD]   (bA, bC, bDQ are MFMA A operands: pitches XLD / QLD)
+    float* bB = bA + SP * XLD;               // [SP][D]
+    float* bC = bB + SP * D;                 // [SP][XLD]
+    float* bQ = bC + SP * XLD;               // [SP][QLD] saved q | k | v
     float* bDQ = bQ + SP * QLD;              // [SP][QLD] d(q | k | v)
     float* mask = bDQ + SP * QLD;            // [SP][D]
-    const int k = tid & 127, g = tid >> 7;
+    constexpr int MT = SP > 16 ? 2 : 1;
     const float dp = a.drop_p;
     for (int i = tid; i < SP * D; i += 256) {
         const int s = i >> 7, d = i & 127;
-        bA[i] = s < S ? a.dY[((long)s * B + b) * D + d] : 0.f;
-        bB[i] = 0.f; bC[i] = 0.f; mask[i] = 1.f;
+        bA[s * XLD + d] = s < S ? a.dY[((long)s * B + b) * D + d] : 0.f;
+        bB[i] = 0.f; bC[s * XLD + d] = 0.f; mask[i] = 1.f;
     }
     for (int i = tid; i < SP * QLD; i += 256) bDQ[i] = 0.f;
     f32x4 wreg[8];
-    float acc[NR];
+    f32x4 acc[MT][2];
     w_issue<8>(a.w[a.L - 1].w2, wreg);
     __syncthreads();
 #pragma unroll 1
@@ -366,68 +366,59 @@ __global__ __launch_bounds__(256, 1) void k_encoder_bwd(const EncFusedBwdArgs a)
         float* lnp = a.lnp + ((long)b * a.L + l) * 4 * D;
         // ---- LayerNorm 2 backward: bA = d x_{l+1} -> bB = d x1 (residual), bC = d f (dropped) -----------------------------------
         if (dp > 0.f) { fill_mask(mask, S, B, b, dp, a.seed, sid + 3); __syncthreads(); }
-        ln_bwd_rows(bA, S, B, b, W.g2, O.xh2, O.rstd2, bB, bC, G.df, mask, Wl, lnp + 2 * D);
+        ln_bwd_rows(bA, XLD, S, B, b, W.g2, O.xh2, O.rstd2, bB, D, bC, XLD, G.df, mask, Wl, lnp + 2 * D);
         // ---- d hact = d f W2 ; d hpre = d hact * drop * act'(hpre) -> bA -------------------------------------------------------
         __syncthreads();
         if (dp > 0.f) fill_mask(mask, S, B, b, dp, a.seed, sid + 2);
-#pragma unroll
-        for (int i = 0; i < NR; ++i) acc[i] = 0.f;
+        zero_acc<MT>(acc);
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
             __syncthreads();
             w_commit<8>(Wl, wreg);
             __syncthreads();
             w_issue<8>(hf == 0 ? W.w2 + HR * D : W.w1, wreg);
-            gemm_t64<NR>(bC, D, hf * HR, g, Wl, k, acc);
+            gemm_t64_mfma<MT>(bC, XLD, hf * HR, Wl, acc);
         }
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int s = g + 2 * i;
-            if (s < S) {
-                const long t = (long)s * B + b;
-                const float x = O.hpre[t * D + k];
-                const float gr = acc[i] * mask[s * D + k];
-                const float dact = a.gelu ? 0.5f * (1.f + erff(x * kInvSqrt2)) + x * 0.3989422804014327f * expf(-0.5f * x * x) : (x > 0.f ? 1.f : 0.f);
-                const float v = gr * dact;
-                bA[s * D + k] = v;
-                G.dhp[t * D + k] = v;
-            }
-        }
+        mfma_results<MT>(acc, S, [&](int s, int, int k, float v0) {
+            const long t = (long)s * B + b;
+            const float x = O.hpre[t * D + k];
+            const float gr = v0 * mask[s * D + k];
+            const float dact = a.gelu ? 0.5f * (1.f + erff(x * kInvSqrt2)) + x * 0.3989422804014327f * expf(-0.5f * x * x) : (x > 0.f ? 1.f : 0.f);
+            const float v = gr * dact;
+            bA[s * XLD + k] = v;
+            G.dhp[t * D + k] = v;
+        });
         // ---- d x1 += d hpre W1 -------------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int i = 0; i < NR; ++i) acc[i] = 0.f;
+        zero_acc<MT>(acc);
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
             __syncthreads();
             w_commit<8>(Wl, wreg);
             __syncthreads();
             w_issue<8>(hf == 0 ? W.w1 + HR * D : W.wo, wreg);
-            gemm_t64<NR>(bA, D, hf * HR, g, Wl, k, acc);
+            gemm_t64_mfma<MT>(bA, XLD, hf * HR, Wl, acc);
         }
-#pragma unroll
-        for (int i = 0; i < NR; ++i) bB[(g + 2 * i) * D + k] += acc[i];
+        mfma_results<MT>(acc, SP, [&](int s, int, int k, float v) { bB[s * D + k] += v; });
         if (dp > 0.f) fill_mask(mask, S, B, b, dp, a.seed, sid + 1);
         __syncthreads();
         // ---- LayerNorm 1 backward: bB = d x1 -> bA = d x_l (residual), bC = d attention-out (dropped) ---------------------------
-        ln_bwd_rows(bB, S, B, b, W.g1, O.xh1, O.rstd1, bA, bC, G.dao, mask, Wl, lnp);
+        ln_bwd_rows(bB, D, S, B, b, W.g1, O.xh1, O.rstd1, bA, XLD, bC, XLD, G.dao, mask, Wl, lnp);
         // ---- d ctx = d ao Wo -> bB ; meanwhile the saved q | k | v come in ---------------------------------------------------
 #pragma unroll 1
         for (int i = tid; i < S * 3 * D; i += 256) {
             const int s = i / (3 * D), d = i - s * 3 * D;
             bQ[s * QLD + d] = O.qkv[((long)s * B + b) * 3 * D + d];
         }
-#pragma unroll
-        for (int i = 0; i < NR; ++i) acc[i] = 0.f;
+        zero_acc<MT>(acc);
 #pragma unroll 1
         for (int hf = 0; hf < 2; ++hf) {
             __syncthreads();
             w_commit<8>(Wl, wreg);
             __syncthreads();
             w_issue<8>(hf == 0 ? W.wo + HR * D : W.win, wreg);
-            gemm_t64<NR>(bC, D, hf * HR, g, Wl, k, acc);
+            gemm_t64_mfma<MT>(bC, XLD, hf * HR, Wl, acc);
         }
-#pragma unroll
-        for (int i = 0; i < NR; ++i) bB[(g + 2 * i) * D + k] = acc[i];
+        mfma_results<MT>(acc, SP, [&](int s, int, int k, float v) { bB[s * D + k] = v; });
         __syncthreads();
         // ---- attention backward: thread (h, s); dS and the dropped probabilities are exchanged through the W image ---------------
         float* xS = Wl;                                   // [H][SMAX][SMAX + 1]
@@ -489,8 +480,7 @@ __global__ __launch_bounds__(256, 1) void k_encoder_bwd(const EncFusedBwdArgs a)
             }
         }
         // ---- d x_l = bA + d qkv Win (six half blocks) ------------------------------------------------------------------------------
-#pragma unroll
-        for (int i = 0; i < NR; ++i) acc[i] = 0.f;
+        zero_acc<MT>(acc);
 #pragma unroll 1
         for (int hf = 0; hf < 6; ++hf) {
             __syncthreads();
@@ -498,15 +488,14 @@ __global__ __launch_bounds__(256, 1) void k_encoder_bwd(const EncFusedBwdArgs a)
             __syncthreads();
             if (hf < 5) w_issue<8>(W.win + (hf + 1) * HR * D, wreg);
             else if (l > 0) w_issue<8>(a.w[l - 1].w2, wreg);
-            gemm_t64<NR>(bDQ, QLD, hf * HR, g, Wl, k, acc);
+            gemm_t64_mfma<MT>(bDQ, QLD, hf * HR, Wl, acc);
         }
-#pragma unroll
-        for (int i = 0; i < NR; ++i) bA[(g + 2 * i) * D + k] += acc[i];
+        mfma_results<MT>(acc, SP, [&](int s, int, int k, float v) { bA[s * XLD + k] += v; });
         __syncthreads();
     }
     for (int i = tid; i < S * D; i += 256) {
         const int s = i >> 7, d = i & 127;
-        a.dX[((long)s * B + b) * D + d] = bA[i];
+        a.dX[((long)s * B + b) * D + d] = bA[s * XLD + d];
     }
 }
 
@@ -535,17 +524,30 @@ __global__ __launch_bounds__(256) void k_encoder_wgrad(const EncWgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float bsum = 0.f;
+    // the next 32 token rows travel in registers while the current ones multiply (round 5: one memory round trip per tile was the kernel:
+    // nine dependent trips for T = 288, 72 us)
+    float xr[16], yr[4];
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = tid + 256 * q, t = i >> 7, c = i & 127;
+            xr[q] = t0 + t < a.T ? J.X[(long)(t0 + t) * D + c] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q, t = i >> 5, n = i & 31;
+            yr[q] = t0 + t < a.T ? J.dY[(long)(t0 + t) * J.ldy + n0 + n] : 0.f;
+        }
+    };
+    issue(0);
     for (int t0 = 0; t0 < a.T; t0 += 32) {
         __syncthreads();
-        for (int i = tid; i < 32 * D; i += 256) {
-            const int t = i >> 7, c = i & 127;
-            Xs[t][c] = t0 + t < a.T ? J.X[(long)(t0 + t) * D + c] : 0.f;
-        }
-        for (int i = tid; i < 32 * 32; i += 256) {
-            const int t = i >> 5, n = i & 31;
-            Ys[t][n & 1][n >> 1] = t0 + t < a.T ? J.dY[(long)(t0 + t) * J.ldy + n0 + n] : 0.f;
-        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int i = tid + 256 * q; Xs[i >> 7][i & 127] = xr[q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = tid + 256 * q, n = i & 31; Ys[i >> 5][n & 1][n >> 1] = yr[q]; }
         __syncthreads();
+        if (t0 + 32 < a.T) issue(t0 + 32);
 #pragma unroll 4
         for (int t = 0; t < 32; ++t) {
             const float x = Xs[t][k];
@@ -568,6 +570,12 @@ __global__ __launch_bounds__(256) void k_encoder_wgrad(const EncWgradArgs a) {
 int rows_bucket(int S) { const int r = (S + 1) / 2; return r <= 3 ? 3 : r <= 5 ? 5 : r <= 8 ? 8 : 11; }
 // dynamic LDS of the forward kernel.  The MFMA products read 16 (32 for the largest bucket) rows of their A operand whatever the padded
 // sequence length: the last operand buffer (hb) is followed by the mask and the validity words; pad so that those reads stay inside.
+size_t bwd_smem(int SP) {               // backward: the last A operand (bDQ) is followed by the mask
+    const int MT = SP > 16 ? 2 : 1;
+    long over = (long)16 * MT * QLD - ((long)SP * QLD + (long)SP * D);
+    if (over < 0) over = 0;
+    return ((size_t)HR * WLD + (size_t)SP * (2 * XLD + 2 * D + 2 * QLD) + (size_t)over) * 4 + 64;
+}
 size_t fwd_smem(int SP) {
     const int MT = SP > 16 ? 2 : 1;
     long over = (long)16 * MT * XLD - ((long)SP * XLD + (long)SP * D + SMAX);
@@ -595,7 +603,7 @@ int launch_fwd(const EncFusedArgs& a, hipStream_t st) {
 template <int HD, int NR>
 int launch_bwd(const EncFusedBwdArgs& a, hipStream_t st) {
     constexpr int SP = 2 * NR;
-    const size_t smem = ((size_t)HR * WLD + (size_t)SP * (4 * D + 2 * QLD)) * 4 + 64;
+    const size_t smem = bwd_smem(SP);
     static bool attr[16] = {};
     int dev = 0;
     TCVN_CHECK(hipGetDevice(&dev));
@@ -619,7 +627,7 @@ bool encoder_fused_ok(int S, int Dm, int H, int L, int norm_first) {
     if ((long)H * S * (S + 1) > 2L * SP * D) return false;                          // score rows alias the token buffers (forward)
     if (2L * H * SMAX * (SMAX + 1) > (long)HR * WLD) return false;                  // dS / dropped-P exchange aliases the weight image (backward)
     const size_t smem_f = fwd_smem(SP);
-    const size_t smem_b = ((size_t)HR * WLD + (size_t)SP * (4 * D + 2 * QLD)) * 4 + 64;
+    const size_t smem_b = bwd_smem(SP);
     return smem_f <= 160 * 1024 && smem_b <= 160 * 1024;
 }
 
