@@ -8,11 +8,12 @@ from transformercvn.options import Options
 from transformercvn.network.trainers.neutrino_full_dense_trainer import NeutrinoFullDenseTrainer
 dev = torch.device("cuda:0")
 opt = Options.load(os.path.join(bench.PKG, "option_files", "tutorial_densenet_synthetic.json"))
-opt.batch_size, opt.num_gpu, opt.hip_precision = 32, 1, (sys.argv[1] if len(sys.argv) > 1 else "bf16")
+BN = int(os.environ.get("TIME_BATCH", "32"))
+opt.batch_size, opt.num_gpu, opt.hip_precision = BN, 1, (sys.argv[1] if len(sys.argv) > 1 else "bf16")
 opt.training_file = "synthetic:64:8"
 model = NeutrinoFullDenseTrainer(opt).to(dev); model.train()
 rt = model.network.hip_runtime(); rt.ensure_bound()
-batch = bench.make_batch(32, 8, 1234, dev)
+batch = bench.make_batch(BN, 8, 1234, dev)
 marks = []
 def wrap(obj, name, label):
     fn = getattr(obj, name)
