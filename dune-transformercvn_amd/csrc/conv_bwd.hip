@@ -502,6 +502,7 @@ int conv_wgrad(const ConvWgradArgs& a, hipStream_t st) {
     }
     if (conv3x3_wgrad_f32_ok(a)) return conv3x3_wgrad_f32(a, st);
     if (conv1x1_wgrad_f32_ok(a)) return conv1x1_wgrad_f32(a, st);
+    if (gemm_tn_f32_ok(a)) return gemm_tn_f32(a, st);
     char nm[96];
     snprintf(nm, sizeof(nm), "k_conv_wgrad<%s,%d,%d>", a.mode == MODE_F32 ? "float" : "bf16", a.fa.amode, a.e.N <= 32 ? 32 : a.e.N <= 64 ? 64 : 128);
     ProfScope ps(nm, 2.0 * a.fa.M * (double)a.e.N * a.fa.K, 0.0, st);

@@ -246,6 +246,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
             if (L.XP[bi] >= 0 && mode == MODE_F32) {  // fp32: the materialised pooled activation of the forward is the weight gradient's operand
                 w.fa.amode = A_1X1; w.fa.A = ws + L.XP[bi]; w.fa.lda = bg.ldp; w.fa.K = bg.ldp; w.fa.C = bg.ldp;
                 w.fa.sc = nullptr; w.fa.sh = nullptr; w.fa.sl = nullptr;
+                w.slab = reinterpret_cast<float*>(ws + L.slab); w.slab_bytes = kSlabBytes;      // split-K slabs of k_gemm_tn_f32 (the stream was drained above)
             }
             if (xp_bf16) {
                 // materialise the output gradient once (+ bias gradient), then dW = ET^T x XP on the TN GEMM
@@ -362,6 +363,7 @@ int DenseNetPlan::backward(int n, const float* d_out, long d_out_ld, char* ws, l
                 w.fa.mode = mode; w.fa.amode = A_1X1; w.fa.A = D; w.fa.lda = bg.ld; w.fa.M = (int)M; w.fa.N = mid; w.fa.K = ls.cin;
                 w.fa.Kp = ef.Kp; w.fa.C = ls.cin; w.fa.H = bg.H; w.fa.W = bg.W;
                 w.fa.sc = sc_of(ls.n1); w.fa.sh = sh_of(ls.n1); w.fa.sl = data[ls.a1];
+                if (mode == MODE_F32) { w.slab = reinterpret_cast<float*>(ws + L.slab); w.slab_bytes = kSlabBytes; }     // k_gemm_tn_f32 (cin % 4 != 0); same stream as every other user
                 if (L.XA[bi][l] >= 0) {
                     const bool par = side_on;
                     char* EY = ws + ((par && (seq & 1)) ? L.ey2 : L.ey);

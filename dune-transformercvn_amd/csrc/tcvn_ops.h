@@ -162,6 +162,8 @@ struct ConvWgradArgs {
                          // the caller folds them into a later reduction launch; the slab must stay untouched until then
 };
 int conv_wgrad(const ConvWgradArgs& a, hipStream_t st);
+bool gemm_tn_f32_ok(const ConvWgradArgs& a);        // gemm_tn_f32.hip: fp32 1x1 weight gradient over an already activated operand (transitions, parity mode)
+int gemm_tn_f32(const ConvWgradArgs& a, hipStream_t st);
 bool conv3x3_wgrad_tile_ok(const ConvWgradArgs& a);
 // fp32 padded-tile 3x3 kernels (conv3x3_f32.hip): parity mode, C = 128 -> N <= 32
 bool conv3x3_fwd_f32_ok(const ConvFwdArgs& a);
