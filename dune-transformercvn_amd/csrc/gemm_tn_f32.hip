@@ -1,10 +1,11 @@
 // fp32 (parity mode) weight gradient of a 1x1 convolution, any channel counts -- the transitions (operand already activated) and the
-// bottleneck layers the 128-output tile kernel does not take (cin % 4 != 0: dense block 5)
+// bottleneck layers (raw operand, activated on the way into LDS)
 // (reference: Transition = BN - PReLU - conv1x1 - AvgPool2, layers/dense_net.py:78-94, and its autograd; the pooled + activated input XP is
 // materialised by the forward pass, densenet.hip):
 //     dW[n][c] += sum_pos eff[pos][n] * XP[pos][c] ,   db[n] += sum_pos eff[pos][n] ,   eff = G + P * x + Q  (EffSrc)
-// Round 5.  The bottleneck tile kernel (k_conv1x1_wgrad_f32: a wave owns 32 output channels over ALL positions) loses on these shapes
-// (80..260 output channels, 160..528 input channels, a quarter of the positions); this is a plain split-K TN GEMM on
+// Round 5.  The bottleneck tile kernel (k_conv1x1_wgrad_f32: a wave owns 32 output channels over ALL positions, closing fp32 atomics) does not
+// cover the transitions' shapes and measured slower than this kernel on its own layers too (9.0 -> 6.8 ms per step over the 68 launches;
+// a 256-input-channel tile variant that halves the re-reads of eff spilled and lost: 9.3 ms).  A plain split-K TN GEMM on
 // v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation): a workgroup owns a 128 x 128 tile of dW and a slice of the positions,
 // 2 x 2 waves of 64 x 64 (four accumulator tiles each); both operands of a 32-position chunk are staged in LDS as [position][channel]
 // (one float per lane and k-step: lane = channel, the two positions of a k-step on the lane halves), the next chunk travels in registers
