@@ -270,21 +270,25 @@ int tcvn_sdxl::backward(int n, const float* d_out, long d_out_ld, char* ws, long
     // zero: backward GroupNorm sums and the kernel-layout weight gradients (forward statistics sit in front of them and stay)
     TCVN_CHECK(hipMemsetAsync(ws + L.bstats, 0, (size_t)(L.zero_end - L.bstats), st));
     std::vector<char> written(bufs.size(), 0);
+    // gradient region of every buffer for THIS call: a residual input that has no contribution yet simply TAKES OVER the region of the output
+    // gradient (same shape; dead once its producer has been processed) instead of receiving a copy of it (round 5: ten device-to-device copies of
+    // up to 2 GB, 3.1 ms per step)
+    std::vector<long> goff(L.grad.begin(), L.grad.end());
     const int last = (int)bufs.size() - 1;
     // the last buffer is the caller's fp32 output; its gradient arrives as fp32 too
-    if ((rc = cast_f32_to(cfg.mode, d_out, d_out_ld, ws + L.grad[last], bufs[last].C, n, bufs[last].C, st))) return rc;
+    if ((rc = cast_f32_to(cfg.mode, d_out, d_out_ld, ws + goff[last], bufs[last].C, n, bufs[last].C, st))) return rc;
     written[last] = 1;
     for (int oi = (int)ops.size() - 1; oi >= 0; --oi) {
         const SOp& o = ops[oi];
         if (!written[o.out]) { fprintf(stderr, "tcvn: sdxl backward: gradient of buffer %d never produced\n", o.out); return -15; }
-        const char* dO = ws + L.grad[o.out];
+        const char* dO = ws + goff[o.out];
         const long rows_in = (long)n * bufs[o.in].H * bufs[o.in].W;
         if (o.kind == OP_GN) {
             GnArgs a{cfg.mode, ws + L.act[o.in], bufs[o.in].C, n, bufs[o.in].H * bufs[o.in].W, bufs[o.in].C, data[o.w], data[o.b], kGnEps, o.act,
                      reinterpret_cast<double*>(ws + L.stats) + (long)o.gn_id * n * 2};
             double* bs = reinterpret_cast<double*>(ws + L.bstats) + (long)o.gn_id * n * 2;
             if ((rc = gn_bwd_reduce(a, dO, bufs[o.out].C, bs, grad[o.w], grad[o.b], st))) return rc;
-            if ((rc = gn_bwd_apply(a, dO, bufs[o.out].C, bs, ws + L.grad[o.in], bufs[o.in].C, written[o.in], st))) return rc;
+            if ((rc = gn_bwd_apply(a, dO, bufs[o.out].C, bs, ws + goff[o.in], bufs[o.in].C, written[o.in], st))) return rc;
             written[o.in] = 1;
         } else {
             SConv g = geom(o, n);
@@ -292,13 +296,14 @@ int tcvn_sdxl::backward(int n, const float* d_out, long d_out_ld, char* ws, long
             if (o.in == 0) { g.hits = last_coords; g.nnz = last_nnz; }
             if ((rc = sconv_wgrad(g, ws + L.act[o.in], dO, g.Cout, reinterpret_cast<float*>(ws + L.gwk[o.conv_id]), grad[o.b], st))) return rc;
             if (o.in != 0) {
-                if ((rc = sconv_dgrad(g, dO, g.Cout, ws + L.wkt[o.conv_id], ws + L.grad[o.in], g.Cin, written[o.in], st))) return rc;
+                if ((rc = sconv_dgrad(g, dO, g.Cout, ws + L.wkt[o.conv_id], ws + goff[o.in], g.Cin, written[o.in], st))) return rc;
                 written[o.in] = 1;
             }
             if (o.res >= 0) {                                            // out = conv(...) + res: the residual receives dOut as is
                 const long rows = (long)n * bufs[o.res].H * bufs[o.res].W;
-                if (written[o.res]) { if ((rc = add_into(cfg.mode, ws + L.grad[o.res], bufs[o.res].C, dO, g.Cout, rows, g.Cout, st))) return rc; }
-                else TCVN_CHECK(hipMemcpyAsync(ws + L.grad[o.res], dO, (size_t)rows * g.Cout * esz, hipMemcpyDeviceToDevice, st));
+                if (written[o.res]) { if ((rc = add_into(cfg.mode, ws + goff[o.res], bufs[o.res].C, dO, g.Cout, rows, g.Cout, st))) return rc; }
+                else if (bufs[o.res].C == g.Cout && rows == (long)n * bufs[o.out].H * bufs[o.out].W) std::swap(goff[o.res], goff[o.out]);      // stream order: this op's kernels read dO first
+                else TCVN_CHECK(hipMemcpyAsync(ws + goff[o.res], dO, (size_t)rows * g.Cout * esz, hipMemcpyDeviceToDevice, st));
                 written[o.res] = 1;
             }
         }
