@@ -858,6 +858,13 @@ __global__ __launch_bounds__(256) void k_sub_reduce(const float* __restrict__ sl
     if (i >= 64 * 576) return;
     float s0 = 0.f, s1 = 0.f;
     int x = 0;
+    for (; x + 7 < nx; x += 8) {                                   // eight slabs requested together (two per trip was a memory round trip per pair:
+        float v[8];                                                // up to 128 dependent trips per launch, 73 launches per step)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = slab[((long)(x + q) * nsub + sub) * (64 * 576) + i];
+        s0 += (v[0] + v[2]) + (v[4] + v[6]);
+        s1 += (v[1] + v[3]) + (v[5] + v[7]);
+    }
     for (; x + 1 < nx; x += 2) {
         s0 += slab[((long)x * nsub + sub) * (64 * 576) + i];
         s1 += slab[((long)(x + 1) * nsub + sub) * (64 * 576) + i];
