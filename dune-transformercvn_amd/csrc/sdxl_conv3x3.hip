@@ -793,7 +793,9 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) out[tap * 64 + (e & 3) + 8 * (e >> 2) + 4 * lh] = acc[tap][e];
     }
-    if (g.bslab == nullptr) return;                                // uniform: general width takes the bias gradient from a column sum
+    if (g.bslab == nullptr) return;                                // uniform
+    const int ncc_ = g.cin / 64;                                   // general width (2-D grid): the sub-blocks of one output-channel group saw the same
+    if ((int)blockIdx.y % ncc_ != 0) return;                       // dOut tiles; the first of them leaves the group's column sums (uniform per workgroup)
     // bias gradient: threads with equal tid & 7 hold the same 8 channels
     __syncthreads();
     float* br = reinterpret_cast<float*>(smem);                    // [32][64]
@@ -803,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void k_sconv3_c64_wgrad(const W64Args g) {
     if (tid < 64) {
         float s = 0.f;
         for (int q = 0; q < 32; ++q) s += br[q * 64 + tid];
-        g.bslab[(long)blockIdx.x * 64 + tid] = s;
+        g.bslab[((long)blockIdx.x * (g.cout / 64) + blockIdx.y / ncc_) * 64 + tid] = s;
     }
 }
 
@@ -874,26 +876,6 @@ __global__ __launch_bounds__(256) void k_sub_reduce(const float* __restrict__ sl
     const int c0 = 64 * (sub % ncc), n0 = 64 * (sub / ncc);
     dWk[(long)(n0 + n) * (9 * cin) + tap * cin + c0 + c] += s0 + s1;
 }
-// dst[c] += column sums of X [rows][C] bf16, C/8 divides 256
-__global__ __launch_bounds__(256) void k_colsum_bf16(const bf16* __restrict__ X, long rows, int C, float* __restrict__ dst) {
-    extern __shared__ float cred[];                                // [256 / (C/8)][C]
-    const int c8 = C >> 3, lanes = 256 / c8;
-    const int cg = threadIdx.x % c8, rl = threadIdx.x / c8;
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long r = (long)blockIdx.x * lanes + rl; r < rows; r += (long)gridDim.x * lanes) {
-        const u16x8 v = *reinterpret_cast<const u16x8*>(X + r * C + cg * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] += bf2f(v[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) cred[rl * C + cg * 8 + j] = s[j];
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float t = 0.f;
-        for (int q = 0; q < lanes; ++q) t += cred[q * C + c];
-        atomicAdd(dst + c, t);
-    }
-}
 }  // namespace
 
 bool sconv3_g_wgrad_ok(const SConv& g, const void* In, const void* dOut, long lddo) {
@@ -908,7 +890,9 @@ int sconv3_g_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk,
     int gx = 512 / nsub;                                           // slab holds 512 sub-block partials; two workgroups per CU
     if (gx > a.ntiles) gx = a.ntiles;
     if (gx < 1) gx = 1;
-    a.slab = g.slab; a.bslab = nullptr;
+    // bias gradient from the kernel's own dOut tiles (round 5; before: a separate column-sum pass over dOut, 73 launches and ~8 GB of reads per step):
+    // one row of cout sums per x-workgroup, behind the 512 weight sub-block slabs (gx * cout <= 512 * 64 floats)
+    a.slab = g.slab; a.bslab = dbias != nullptr ? g.slab + 512L * 64 * 576 : nullptr;
     static bool attr = false;
     if (!attr) {
         TCVN_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sconv3_c64_wgrad<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_SMEM));
@@ -927,14 +911,7 @@ int sconv3_g_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk,
     TCVN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sub_reduce, dim3((64 * 576 + 255) / 256, nsub), dim3(256), 0, st, a.slab, gx, nsub, ncc, g.Cin, dWk);
     TCVN_LAUNCH_CHECK();
-    if (dbias != nullptr) {
-        const long rows = (long)g.n * g.Hin * g.Win;
-        const int lanes = 256 / (g.Cout / 8);
-        long nb = (rows + lanes * 16 - 1) / (lanes * 16);
-        if (nb > 512) nb = 512;
-        hipLaunchKernelGGL(k_colsum_bf16, dim3((int)nb), dim3(256), (size_t)lanes * g.Cout * 4, st, reinterpret_cast<const bf16*>(dOut), rows, g.Cout, dbias);
-        TCVN_LAUNCH_CHECK();
-    }
+    if (dbias != nullptr) return slab_reduce(a.bslab, gx, g.Cout, dbias, st);
     return 0;
 }
 
@@ -996,19 +973,12 @@ int sconv3_s2_wgrad(const SConv& g, const void* In, const void* dOut, float* dWk
     int gx = 512 / nsub;
     if (gx > a.ntiles) gx = a.ntiles;
     if (gx < 1) gx = 1;
-    a.slab = g.slab; a.bslab = nullptr;
+    a.slab = g.slab; a.bslab = dbias != nullptr ? g.slab + 512L * 64 * 576 : nullptr;
     hipLaunchKernelGGL((k_sconv3_c64_wgrad<2, false>), dim3(gx, nsub), dim3(256), (size_t)(5 * 65 * 128 + 2 * TW * 128), st, a);
     TCVN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sub_reduce, dim3((64 * 576 + 255) / 256, nsub), dim3(256), 0, st, a.slab, gx, nsub, ncc, g.Cin, dWk);
     TCVN_LAUNCH_CHECK();
-    if (dbias != nullptr) {
-        const long rows = (long)g.n * g.Ho * g.Wo;
-        const int lanes = 256 / (g.Cout / 8);
-        long nb = (rows + lanes * 16 - 1) / (lanes * 16);
-        if (nb > 512) nb = 512;
-        hipLaunchKernelGGL(k_colsum_bf16, dim3((int)nb), dim3(256), (size_t)lanes * g.Cout * 4, st, reinterpret_cast<const bf16*>(dOut), rows, g.Cout, dbias);
-        TCVN_LAUNCH_CHECK();
-    }
+    if (dbias != nullptr) return slab_reduce(a.bslab, gx, g.Cout, dbias, st);
     return 0;
 }
 
